@@ -1,0 +1,217 @@
+/*
+ * gogp_hip.h -- C ABI of the MI355X-native GP-regression hot path.
+ *
+ * This is the drop-in boundary for infergo-ml/gogp's gp.GP hot path
+ * (reference: gp/gp.go).  Every entry point names the reference interface it
+ * replaces.  The library behind it (libgogp_hip.so) is hand-written HIP for
+ * gfx950; there is no CPU fallback: if no HIP device is usable every compute
+ * entry point returns GOGP_EHIP.
+ *
+ * Conventions
+ *   - all functions are extern "C", return an int status (GOGP_OK == 0),
+ *     take plain pointers and sizes; no C++/torch types cross the boundary;
+ *   - host pointers are borrowed for the duration of the call only (cgo rule:
+ *     no Go pointer is retained); device memory is owned by the handle;
+ *   - a handle is NOT safe for concurrent use (same as a gp.GP value, whose
+ *     methods mutate its fields: gp/gp.go:84,384-385); different handles may
+ *     be used from different threads;
+ *   - matrices are row-major doubles.
+ */
+#ifndef GOGP_HIP_H
+#define GOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------- */
+#define GOGP_OK 0
+#define GOGP_EARG 1   /* bad argument (wrong length, NULL, unknown kind)       */
+#define GOGP_ENOTPD 2 /* K not positive definite: gp/gp.go:228-230 Factorize   */
+#define GOGP_EHIP 3   /* HIP runtime error / no device / extension unusable    */
+#define GOGP_ESTATE 4 /* call order (Gradient before Observe, ...)             */
+#define GOGP_ENOMEM 5
+
+/* ---- kernel descriptors --------------------------------------------------
+ * The reference accepts any Go value implementing
+ *     type Kernel interface { Observe([]float64) float64; NTheta() int }
+ * (gp/gp.go:14-17) and calls it once per pair (gp/gp.go:110-111).  A device
+ * path needs a closed description instead: the similarity kernel is a SUM of
+ * up to GOGP_MAX_TERMS terms, each  c * f(r)  with f one of the reference's
+ * primitives (kernel/kernel.go).  This covers every kernel the reference
+ * tree defines:
+ *   kernel.Normal/Matern32/Matern52/Periodic       (kernel/kernel.go:23-92)
+ *   c*Matern32                      (tutorial/barebones/kernel/kernel.go:14-16)
+ *   c1*Matern52(l1)+c2*Periodic(l2,10p) (tutorial/hyperpriors/kernel/kernel.go:12-25)
+ * For NDim > 1 (the reference primitives are 1-D, kernel/kernel.go:15-17) the
+ * distance is  r^2 = sum_d ((xa_d-xb_d)/l_d)^2  (all l_d equal unless ard),
+ * which reduces to the reference formulas at NDim == 1.
+ */
+#define GOGP_MAX_TERMS 4
+#define GOGP_MAX_NDIM 64
+
+enum gogp_simil_kind {
+  GOGP_K_NORMAL = 0,            /* exp(-r^2/2)            kernel/kernel.go:23-26 */
+  GOGP_K_MATERN32 = 1,          /* (1+s3 r)exp(-s3 r)     kernel/kernel.go:70-73 */
+  GOGP_K_MATERN52 = 2,          /* (1+s5 r+1*r^2)exp(-s5 r): the reference's Go
+                                   constant expression 5/3 is INTEGER division,
+                                   i.e. 1 (kernel/kernel.go:91,
+                                   kernel/ad/kernel.go:130)                      */
+  GOGP_K_MATERN52_TEXTBOOK = 3, /* (1+s5 r+(5/3) r^2)exp(-s5 r)                  */
+  GOGP_K_PERIODIC = 4           /* exp(-2 d^2), d=sin(pi|dx|/p)/l
+                                                          kernel/kernel.go:44-47 */
+};
+
+enum gogp_noise_kind {
+  GOGP_NOISE_CONSTANT = 0, /* kernel.ConstantNoise(std): var=std^2, NTheta=0
+                              kernel/noise.go:21-34                             */
+  GOGP_NOISE_UNIFORM = 1   /* scale*kernel.UniformNoise: var=scale*std^2,
+                              NTheta=1  kernel/noise.go:39-53; scale as in
+                              tutorial/barebones/kernel/kernel.go:25-31         */
+};
+
+typedef struct gogp_term {
+  int32_t kind;       /* enum gogp_simil_kind                                   */
+  int32_t scale_idx;  /* index in ThetaSimil of the output scale c; -1: c == 1  */
+  int32_t len_idx;    /* index in ThetaSimil of the (first) length scale        */
+  int32_t ard;        /* 0: one length scale; 1: ndim consecutive length scales */
+  int32_t period_idx; /* GOGP_K_PERIODIC: index of the period parameter         */
+  int32_t reserved;
+  double period_mult; /* effective period = period_mult * theta[period_idx]
+                         (the 10*x[p] of tutorial/hyperpriors/kernel/kernel.go:24) */
+} gogp_term;
+
+typedef struct gogp_desc {
+  int32_t ndim;         /* gp.GP.NDim                      gp/gp.go:22          */
+  int32_t nterms;       /* 1..GOGP_MAX_TERMS                                    */
+  int32_t ntheta_simil; /* gp.GP.Simil.NTheta()                                 */
+  int32_t noise_kind;   /* enum gogp_noise_kind; gp.GP.Noise; nil => CONSTANT
+                           with std 1e-5 (gp/gp.go:43-48)                       */
+  double noise_std;     /* CONSTANT: the std                                    */
+  double noise_scale;   /* UNIFORM: variance = noise_scale * std^2              */
+  gogp_term terms[GOGP_MAX_TERMS];
+} gogp_desc;
+
+typedef struct gogp_handle gogp_handle;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Validate a descriptor; returns GOGP_OK or GOGP_EARG.  Pure host code. */
+int gogp_desc_check(const gogp_desc *desc);
+
+/* Number of noise parameters, Noise.NTheta(): 0 or 1. */
+int gogp_desc_ntheta_noise(const gogp_desc *desc);
+
+/* Create a handle on HIP device `device` (-1: the current device).
+ * Replaces: constructing a gp.GP{NDim,Simil,Noise} value (gp/gp.go:20-24). */
+int gogp_create(const gogp_desc *desc, int device, gogp_handle **out);
+void gogp_destroy(gogp_handle *h);
+
+/* Last error text for this handle (never NULL). With h == NULL: the text of
+ * the last failed gogp_create on this thread. */
+const char *gogp_last_error(const gogp_handle *h);
+
+/* After GOGP_ENOTPD: 0-based index of the failing pivot, else -1. */
+int64_t gogp_notpd_index(const gogp_handle *h);
+
+/* ---- data ------------------------------------------------------------------
+ * Replaces: assigning gp.GP.X ([][]float64, n slices of NDim) and gp.GP.Y
+ * (gp/gp.go:27-28,84).  X is packed row-major n x ndim by the caller's shim.
+ * The data are copied to the device; n == 0 is legal (gp/gp.go:101-104). */
+int gogp_set_data(gogp_handle *h, const double *X, const double *y, int64_t n);
+
+/* Same, but X and y already live in device memory of the handle's device
+ * (used by bench.py so the timed region starts with inputs resident in HBM). */
+int gogp_set_data_device(gogp_handle *h, const double *dX, const double *dy,
+                         int64_t n);
+
+/* ---- the hot path ----------------------------------------------------------*/
+
+/* gp.GP.Absorb (gp/gp.go:80-87) minus the data assignment (gogp_set_data):
+ * Gram build (gp/gp.go:109-156,220-225), Cholesky (gp/gp.go:228), alpha
+ * (gp/gp.go:232-236), WITHOUT gradient.  theta_* are natural-scale
+ * ThetaSimil/ThetaNoise (gp/gp_test.go:29).  Non-PD => GOGP_ENOTPD. */
+int gogp_absorb(gogp_handle *h, const double *theta_simil,
+                const double *theta_noise);
+
+/* gp.GP.Observe, hyperparameters-only form (gp/gp.go:370-373,374-413):
+ * x = log-transformed [ThetaSimil | ThetaNoise] (len P); X, Y as set by
+ * gogp_set_data.  Computes exp(x), Gram, Cholesky, alpha, and returns
+ * LML (gp/gp.go:244-253) in *lml.  Unlike the reference x is NOT mutated
+ * (the reference exp()s and log()s it back in place, gp/gp.go:378-381,
+ * 408-410).  A following gogp_gradient returns d LML / d x.
+ * Errors are returned as codes; the Go shim turns them into the reference's
+ * panic (gp/gp.go:402-405). */
+int gogp_observe(gogp_handle *h, const double *x, int64_t len, double *lml);
+
+/* gp.GP.Observe, full form (gp/gp.go:366-369,386-397): x = [log theta (P) |
+ * x_0..x_{n-1} (ndim each) | y_0..y_{n-1}], n = (len-P)/(ndim+1); replaces the
+ * handle's data by the inputs/outputs carried in x.  len must equal
+ * P + n*(ndim+1) for an integer n (reference: panic("len(x)"), gp/gp.go:398-400). */
+int gogp_observe_full(gogp_handle *h, const double *x, int64_t len, double *lml);
+
+/* gp.GP.LML (gp/gp.go:244-253) of the last absorb/observe; 0 when n == 0. */
+int gogp_lml(gogp_handle *h, double *lml);
+
+/* gp.GP.Gradient (gp/gp.go:418-499): gradient of LML w.r.t. the argument of
+ * the last gogp_observe[_full]: P entries d/d log theta, then -- after
+ * gogp_observe_full -- n*ndim entries d/d x_i,d and n entries d/d y_i = -alpha_i
+ * (gp/gp.go:488-493).  `len` must be that length.  n == 0 => zeros
+ * (gp/gp.go:427-430). */
+int gogp_gradient(gogp_handle *h, double *grad, int64_t len);
+
+/* gp.GP.Produce (gp/gp.go:258-360): predictive mean and standard deviation of
+ * the latent function at m points Z (row-major m x ndim).  sigma_j =
+ * sqrt(k(z_j,z_j) - (Kstar^T K^-1 Kstar)_jj), unclamped like the reference
+ * (gp/gp.go:356: a rounding-negative argument yields NaN).  With no
+ * observations: mu = 0, sigma = sqrt(prior) (gp/gp.go:343-347). */
+int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *mu,
+                 double *sigma);
+
+/* ---- cached state (gp.GP.L, gp.GP.Alpha: gp/gp.go:35-36,255-257) ---------- */
+int64_t gogp_n(const gogp_handle *h);
+int gogp_get_alpha(gogp_handle *h, double *alpha /* n */);
+/* Lower Cholesky factor, row-major n x n, upper triangle zero-filled.
+ * (gonum stores U = L^T; the Go shim transposes when filling gp.GP.L.) */
+int gogp_get_factor(gogp_handle *h, double *L /* n*n */);
+/* Restore stored results so that gogp_produce works without re-absorbing
+ * ("Produce on stored results", gp/gp.go:255-257). */
+int gogp_set_factor(gogp_handle *h, const double *theta_simil,
+                    const double *theta_noise, const double *L /* n*n */,
+                    const double *alpha /* n */);
+
+/* ---- measurement hooks (bench.py / tests; not part of the reference API) --- */
+
+/* Enable (1) / disable (0) HIP-event timing of every launch of the dominant
+ * kernel family (the fp64 MFMA GEMM/SYRK tile kernel) on the stream it is
+ * launched on. */
+int gogp_profile_enable(gogp_handle *h, int on);
+/* Sum of event-measured durations (ms) and number of launches since the last
+ * reset; resets the accumulators. */
+int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
+                      double *gemm_flops);
+
+/* Tuning knobs: name in {"lookahead","nb"}; returns GOGP_EARG if unknown. */
+int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
+
+/* Library build info: "gogp_hip <version> gfx950 ..." */
+const char *gogp_version(void);
+
+/* Micro-benchmark used to calibrate the fp64 MFMA roofline: issues `iters`
+ * back-to-back v_mfma_f64_16x16x4_f64 per wave on every SIMD and returns the
+ * achieved TFLOP/s. */
+int gogp_mfma_f64_peak(int device, int iters, double *tflops);
+
+/* Stand-alone fp64 GEMM test hook: C(MxN,row-major) = beta*C + alpha*A(MxK)*B(NxK)^T
+ * on host buffers (copied to the device and back); M,N multiples of 128,
+ * K multiple of 16.  Exists so the tile kernel can be parity-tested in
+ * isolation against a host reference. */
+int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
+                       const double *A, const double *B, double beta, double *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOGP_HIP_H */

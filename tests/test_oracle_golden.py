@@ -1,0 +1,200 @@
+"""Pin the CPU oracle against the reference's own known answers.
+
+Mirrors gp/gp_test.go: TestProduce (gp_test.go:14-165) and TestElementalModel
+(gp_test.go:173-269), case by case, with the reference's tolerances.  CPU only.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gogp_amd import kernel
+from oracle.oracle import FastOracle, Oracle
+
+
+def _noise(spec):
+    if spec["kind"] == "constant":
+        return kernel.ConstantNoise(spec["std"])
+    return kernel.UniformNoise
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    with open(os.path.join(golden_dir, "gp_test_known_answers.json")) as f:
+        return json.load(f)
+
+
+def test_produce_known_answers(known):
+    # gp_test.go:133-162
+    for c in known["produce"]:
+        for cls in (Oracle, FastOracle):
+            gp = cls(1, kernel.Normal, _noise(c["noise"]))
+            gp.Absorb(np.array(c["x"], dtype=float).reshape(-1, 1), c["y"], c["theta_simil"])
+            mu, sigma = gp.Produce(c["z"])
+            assert len(mu) == len(c["mu"]) and len(sigma) == len(c["sigma"])
+            for got, want in zip(mu, c["mu"]):
+                assert abs(got - want) <= 1e-6, (c["name"], cls.__name__, mu)
+            for got, want in zip(sigma, c["sigma"]):
+                # 'self'/'two selves': variance - covariance rounds around 0; the
+                # reference lets a NaN pass (math.Abs(NaN-x) > 1e-6 is false)
+                if math.isnan(got):
+                    assert want == 0
+                    continue
+                assert abs(got - want) <= 1e-6, (c["name"], cls.__name__, sigma)
+
+
+def test_elemental_model_known_answers(known):
+    # gp_test.go:231-267
+    dx, eps = known["fd"]["dx"], known["fd"]["eps"]
+    for c in known["elemental"]:
+        gp = Oracle(1, kernel.Normal, _noise(c["noise"]))
+        x = np.array(c["x"], dtype=float)
+        ll = gp.Observe(x)
+        dll = gp.Gradient()
+        assert abs(ll - c["ll"]) < 1e-6, c["name"]
+        assert len(dll) == len(x)
+        for j in range(len(x)):
+            xj = x.copy()
+            xj[j] += dx
+            llj = gp.Observe(xj)
+            assert abs(dll[j] - (llj - ll) / dx) <= eps, (c["name"], j)
+        # hyperparameters-only form, gp_test.go:254-267
+        P = gp.ns + gp.nn
+        n = (len(x) - P) // 2
+        gp.set_data(x[P:P + n].reshape(-1, 1), x[P + n:])
+        ll2 = gp.Observe(x[:P])
+        dll2 = gp.Gradient()
+        assert abs(ll2 - c["ll"]) < 1e-6
+        assert len(dll2) == P
+        np.testing.assert_allclose(dll2, dll[:P], rtol=1e-12, atol=1e-12)
+        # the numpy twin agrees (hyperparameters-only)
+        fo = FastOracle(1, kernel.Normal, _noise(c["noise"]))
+        fo.set_data(x[P:P + n].reshape(-1, 1), x[P + n:])
+        assert abs(fo.Observe(x[:P]) - c["ll"]) < 1e-6
+        np.testing.assert_allclose(fo.Gradient(), dll[:P], rtol=1e-9, atol=1e-10)
+
+
+def test_observe_leaves_argument_as_reference_does():
+    # gp/gp.go:378-381,408-410: exp then log in place, <= 1 ulp drift
+    gp = Oracle(1, kernel.Normal, kernel.UniformNoise)
+    x = np.array([0.3, -1.2, 0.0, 1.0, 1.0, -1.0])
+    x0 = x.copy()
+    gp.Observe(x)
+    np.testing.assert_allclose(x, x0, rtol=0, atol=4e-16)
+
+
+def test_len_x_panics_like_reference():
+    # gp/gp.go:398-400
+    gp = Oracle(2, kernel.Normal, kernel.ConstantNoise(0.1))
+    with pytest.raises(ValueError):
+        gp.Observe(np.zeros(1 + 4))  # 4 leftovers, not a multiple of NDim+1 = 3
+
+
+@pytest.mark.parametrize("name,simil,ns", [
+    ("normal", kernel.Normal, 1),
+    ("matern32", kernel.Matern32, 1),
+    ("matern52", kernel.Matern52, 1),
+    ("matern52tb", kernel.Matern52Textbook, 1),
+    ("periodic", kernel.Periodic, 2),
+    ("scaled_m32", kernel.Scaled(kernel.Matern32), 2),
+    ("hyperpriors", kernel.Sum([kernel.Scaled(kernel.Matern52),
+                                kernel.Scaled(kernel.PeriodScaled(kernel.Periodic, 10.0))],
+                               order=[0, 2, 1, 3, 4]), 5),
+])
+def test_kernel_value_and_tape_gradient(name, simil, ns):
+    """Closed-form partials == central finite differences of the value, and the
+    value == the host kernel's Observe (kernel/kernel.go formulas)."""
+    rng = np.random.default_rng(5)
+    assert simil.NTheta() == ns
+    gp = Oracle(1, simil, None)
+    for _ in range(20):
+        theta = rng.uniform(0.5, 2.0, ns)
+        xa, xb = rng.normal(size=1), rng.normal(size=1)
+        v, g = gp.simil(theta, xa, xb, with_grad=True)
+        assert abs(v - simil.Observe(list(theta) + list(xa) + list(xb))) < 1e-14
+        args = np.concatenate([theta, xa, xb])
+        for i in range(len(args)):
+            h = 1e-6
+            ap, am = args.copy(), args.copy()
+            ap[i] += h
+            am[i] -= h
+            fd = (simil.Observe(list(ap)) - simil.Observe(list(am))) / (2 * h)
+            assert abs(fd - g[i]) < 1e-7, (name, i, fd, g[i])
+
+
+def test_matern52_reference_coefficient_is_one():
+    # kernel/kernel.go:91: 5/3 is integer division in Go
+    d = 0.7
+    want = (1 + kernel.SQRT5 * d + 1 * d * d) * math.exp(-kernel.SQRT5 * d)
+    assert abs(kernel.Matern52.Observe([1.0, 0.0, d]) - want) < 1e-15
+    tb = (1 + kernel.SQRT5 * d + 5.0 / 3.0 * d * d) * math.exp(-kernel.SQRT5 * d)
+    assert abs(kernel.Matern52Textbook.Observe([1.0, 0.0, d]) - tb) < 1e-15
+
+
+@pytest.mark.parametrize("simil,ndim,ntheta", [
+    (kernel.Scaled(kernel.Normal), 3, 2),
+    (kernel.Scaled(kernel.ARD(kernel.Normal, 3)), 3, 4),
+    (kernel.Scaled(kernel.Matern32), 2, 2),
+    (kernel.Scaled(kernel.Matern52), 2, 2),
+    (kernel.Sum([kernel.Scaled(kernel.Matern52Textbook), kernel.Scaled(kernel.Periodic)]), 1, 5),
+])
+def test_fast_oracle_matches_faithful(simil, ndim, ntheta):
+    """The W-matrix twin reproduces the faithful 1/2 tr(aa^T dK - K^-1 dK)."""
+    rng = np.random.default_rng(11)
+    n = 40
+    X = rng.uniform(0, 1, (n, ndim))
+    y = np.sin(X.sum(1) * 3) + 0.1 * rng.normal(size=n)
+    noise = kernel.ScaledNoise(0.5)
+    a, b = Oracle(ndim, simil, noise), FastOracle(ndim, simil, noise, block=16)
+    assert simil.NTheta() == ntheta
+    x = np.log(rng.uniform(0.5, 1.5, ntheta + 1))
+    a.set_data(X, y)
+    b.set_data(X, y)
+    la, lb = a.Observe(x), b.Observe(x)
+    assert abs(la - lb) < 1e-9 * max(1, abs(la))
+    np.testing.assert_allclose(b.Gradient(), a.Gradient(), rtol=1e-8, atol=1e-9)
+    Z = rng.uniform(0, 1, (7, ndim))
+    ma, sa = a.Produce(Z)
+    mb, sb = b.Produce(Z)
+    np.testing.assert_allclose(mb, ma, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(sb, sa, rtol=1e-7, atol=1e-9)
+
+
+def test_withobs_gradient_matches_fd():
+    """Inputs/outputs gradient of the full form (gp/gp.go:118-129,488-493) on a
+    D=2 Matern kernel against central differences."""
+    rng = np.random.default_rng(3)
+    n, D = 6, 2
+    simil = kernel.Scaled(kernel.Matern52)
+    gp = Oracle(D, simil, kernel.UniformNoise)
+    x = np.concatenate([np.log([1.3, 0.8, 0.3]), rng.normal(size=n * D), rng.normal(size=n)])
+    ll = gp.Observe(x)
+    g = gp.Gradient()
+    assert len(g) == len(x)
+    for j in range(len(x)):
+        h = 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[j] += h
+        xm[j] -= h
+        fd = (gp.Observe(xp) - gp.Observe(xm)) / (2 * h)
+        assert abs(fd - g[j]) < 1e-6 * max(1.0, abs(fd)), j
+    assert np.isfinite(ll)
+
+
+def test_barebones_csv_config1(golden_dir):
+    """BASELINE config 1 plumbing: tutorial/data/barebones.csv with the barebones
+    kernel c*Matern32 + 0.01*UniformNoise (tutorial/barebones/kernel/kernel.go)."""
+    data = np.loadtxt(os.path.join(golden_dir, "barebones.csv"), delimiter=",")
+    X, y = data[:, :1], data[:, 1]
+    y = (y - y.mean()) / y.std()  # tutorial/tutorial.go:78-86
+    simil = kernel.Scaled(kernel.Matern32)
+    noise = kernel.ScaledNoise(0.01)
+    a, b = Oracle(1, simil, noise), FastOracle(1, simil, noise)
+    a.set_data(X, y)
+    b.set_data(X, y)
+    x = np.zeros(3)
+    la, lb = a.Observe(x), b.Observe(x)
+    assert abs(la - lb) < 1e-9
+    np.testing.assert_allclose(b.Gradient(), a.Gradient(), rtol=1e-8, atol=1e-9)
