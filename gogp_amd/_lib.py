@@ -1,0 +1,84 @@
+"""ctypes loader of libgogp_hip.so (the C ABI of include/gogp_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a
+symbol cannot be bound, importing the binding raises.  Nothing under oracle/
+is ever imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+from .kernel import CDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgogp_hip.so")
+
+GOGP_OK, GOGP_EARG, GOGP_ENOTPD, GOGP_EHIP, GOGP_ESTATE, GOGP_ENOMEM = 0, 1, 2, 3, 4, 5
+
+#: every symbol include/gogp_hip.h declares: (name, restype, argtypes)
+_dp = ctypes.POINTER(ctypes.c_double)
+_i64 = ctypes.c_int64
+_h = ctypes.c_void_p
+_descp = ctypes.POINTER(CDesc)
+SYMBOLS = [
+    ("gogp_desc_check", ctypes.c_int, [_descp]),
+    ("gogp_desc_ntheta_noise", ctypes.c_int, [_descp]),
+    ("gogp_create", ctypes.c_int, [_descp, ctypes.c_int, ctypes.POINTER(_h)]),
+    ("gogp_destroy", None, [_h]),
+    ("gogp_last_error", ctypes.c_char_p, [_h]),
+    ("gogp_notpd_index", _i64, [_h]),
+    ("gogp_set_data", ctypes.c_int, [_h, _dp, _dp, _i64]),
+    ("gogp_set_data_device", ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_void_p, _i64]),
+    ("gogp_absorb", ctypes.c_int, [_h, _dp, _dp]),
+    ("gogp_observe", ctypes.c_int, [_h, _dp, _i64, _dp]),
+    ("gogp_observe_full", ctypes.c_int, [_h, _dp, _i64, _dp]),
+    ("gogp_lml", ctypes.c_int, [_h, _dp]),
+    ("gogp_gradient", ctypes.c_int, [_h, _dp, _i64]),
+    ("gogp_produce", ctypes.c_int, [_h, _dp, _i64, _dp, _dp]),
+    ("gogp_n", _i64, [_h]),
+    ("gogp_get_alpha", ctypes.c_int, [_h, _dp]),
+    ("gogp_get_factor", ctypes.c_int, [_h, _dp]),
+    ("gogp_set_factor", ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
+    ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
+    ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp]),
+    ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
+    ("gogp_version", ctypes.c_char_p, []),
+    ("gogp_mfma_f64_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
+    ("gogp_test_dgemm_nt", ctypes.c_int,
+     [ctypes.c_int, _i64, _i64, _i64, ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into gogp_amd/libgogp_hip.so
+    (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8", "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build did not produce %s" % LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The bound library.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(gogp_amd has no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            f = getattr(L, name)  # AttributeError if the symbol is not exported
+            f.restype = restype
+            f.argtypes = argtypes
+        _lib = L
+    return _lib

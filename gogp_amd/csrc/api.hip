@@ -1,0 +1,763 @@
+// api.hip -- C ABI (include/gogp_hip.h) and orchestration of the hot path.
+//
+// Data layout in HBM (all fp64, row-major, leading dimension npad):
+//   npad = N rounded up to a multiple of 256; rows/cols >= N are identity
+//          padding, so every kernel works on whole 128x128 tiles.
+//   bufA : Gram matrix K (lower triangle) -> destroyed in place by the
+//          trailing updates of the blocked Cholesky; during Gradient it is
+//          re-used for R (right-hand side of the triangular inverse) and
+//          finally holds K^-1 (lower triangle).
+//   bufL : the lower Cholesky factor L (gp.GP.L, gp/gp.go:35).
+//   bufY : Y = L^-T (upper triangular), allocated on the first Gradient.
+//   Dinv : inverse of every 128x128 diagonal block of L (npad/128 blocks).
+//   X (npad x D), y, z = L^-1 y, alpha = K^-1 y (gp.GP.Alpha, gp/gp.go:36).
+//
+// Step list of one Observe + Gradient (reference call stack: SURVEY.md 3.1):
+//   gram_lower -> per 256-panel { diag128, TRSM-as-GEMM, half-panel update,
+//   diag128, TRSM-as-GEMM, SYRK K=256 } -> forward solve -> LML scalars
+//   -> [Gradient] identity fill, per panel { Y=R*Dinv^T x2, updates } ->
+//   LAUUM (K^-1 = Y Y^T) -> backward solve (alpha) -> fused gradient reduce.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+
+
+using namespace gogp;
+
+static thread_local std::string g_create_error;
+
+struct gogp_handle {
+  gogp_desc desc;
+  int device = 0;
+  int ns = 0, nn = 0, P = 0, D = 0;
+  int ard_dims = 0;
+  int64_t n = 0, npad = 0;
+  int nblk = 0;  // 128-blocks
+  // device buffers
+  double *dX = nullptr, *dy = nullptr;
+  double *bufA = nullptr, *bufL = nullptr, *bufY = nullptr, *Dinv = nullptr;
+  double *z = nullptr, *w = nullptr, *alpha = nullptr;
+  double *scalars = nullptr;  // 8 doubles
+  long long *info = nullptr;
+  double *gpart = nullptr, *gout = nullptr;
+  DevParams *devP = nullptr;
+  DevParams *hostP = nullptr;  // pinned
+  double *hscal = nullptr;     // pinned staging, NACC + 16 doubles
+  int64_t cap_npad = 0;        // allocation size of the N-dependent buffers
+  // produce workspace
+  double *dZ = nullptr, *KsT = nullptr, *Vt = nullptr, *pvec = nullptr;
+  int64_t cap_m = 0, cap_mp_npad = 0;
+  hipStream_t s = nullptr;
+  // state
+  std::vector<double> theta_s, theta_n;
+  bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
+  bool observed = false, with_obs = false;
+  double lml = 0.0;
+  std::vector<double> grad_cache;
+  bool grad_valid = false;
+  int64_t notpd = -1;
+  std::string err;
+  GemmProfile prof;
+};
+
+#define HIPCHK(h, call)                                                                \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      char buf_[512];                                                                  \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+               __FILE__, __LINE__);                                                    \
+      (h)->err = buf_;                                                                 \
+      return (e_ == hipErrorOutOfMemory) ? GOGP_ENOMEM : GOGP_EHIP;                     \
+    }                                                                                  \
+  } while (0)
+
+static int fail(gogp_handle *h, int code, const char *msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+// ---- descriptor helpers -------------------------------------------------------
+extern "C" int gogp_desc_ntheta_noise(const gogp_desc *d) {
+  return (d && d->noise_kind == GOGP_NOISE_UNIFORM) ? 1 : 0;
+}
+
+extern "C" int gogp_desc_check(const gogp_desc *d) {
+  if (!d) return GOGP_EARG;
+  if (d->ndim < 1 || d->ndim > GOGP_MAX_NDIM) return GOGP_EARG;
+  if (d->nterms < 1 || d->nterms > GOGP_MAX_TERMS) return GOGP_EARG;
+  if (d->ntheta_simil < 1 || d->ntheta_simil > GOGP_MAX_NDIM + 8) return GOGP_EARG;
+  if (d->noise_kind != GOGP_NOISE_CONSTANT && d->noise_kind != GOGP_NOISE_UNIFORM)
+    return GOGP_EARG;
+  int nard = 0;
+  for (int t = 0; t < d->nterms; ++t) {
+    const gogp_term &T = d->terms[t];
+    if (T.kind < GOGP_K_NORMAL || T.kind > GOGP_K_PERIODIC) return GOGP_EARG;
+    if (T.scale_idx >= d->ntheta_simil || T.scale_idx < -1) return GOGP_EARG;
+    const int nlen = T.ard ? d->ndim : 1;
+    if (T.len_idx < 0 || T.len_idx + nlen > d->ntheta_simil) return GOGP_EARG;
+    if (T.kind == GOGP_K_PERIODIC) {
+      if (T.period_idx < 0 || T.period_idx >= d->ntheta_simil) return GOGP_EARG;
+      if (!(T.period_mult > 0)) return GOGP_EARG;
+    }
+    if (T.ard) ++nard;
+  }
+  if (nard > 1) return GOGP_EARG;  // one ARD term per kernel (grad.hip accumulators)
+  return GOGP_OK;
+}
+
+extern "C" const char *gogp_version(void) {
+  return "gogp_hip 0.1 gfx950 fp64-mfma(v_mfma_f64_16x16x4_f64) tile128 panel256";
+}
+
+extern "C" const char *gogp_last_error(const gogp_handle *h) {
+  if (!h) return g_create_error.c_str();
+  return h->err.c_str();
+}
+
+extern "C" int64_t gogp_notpd_index(const gogp_handle *h) { return h ? h->notpd : -1; }
+extern "C" int64_t gogp_n(const gogp_handle *h) { return h ? h->n : 0; }
+
+// ---- lifecycle ---------------------------------------------------------------------
+static void free_n_buffers(gogp_handle *h) {
+  (void)hipFree(h->dX);
+  (void)hipFree(h->dy);
+  (void)hipFree(h->bufA);
+  (void)hipFree(h->bufL);
+  (void)hipFree(h->bufY);
+  (void)hipFree(h->Dinv);
+  (void)hipFree(h->z);
+  (void)hipFree(h->w);
+  (void)hipFree(h->alpha);
+  (void)hipFree(h->gpart);
+  h->dX = h->dy = h->bufA = h->bufL = h->bufY = h->Dinv = nullptr;
+  h->z = h->w = h->alpha = h->gpart = nullptr;
+  h->cap_npad = 0;
+}
+
+static void free_m_buffers(gogp_handle *h) {
+  (void)hipFree(h->dZ);
+  (void)hipFree(h->KsT);
+  (void)hipFree(h->Vt);
+  (void)hipFree(h->pvec);
+  h->dZ = h->KsT = h->Vt = h->pvec = nullptr;
+  h->cap_m = h->cap_mp_npad = 0;
+}
+
+extern "C" void gogp_destroy(gogp_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->s) (void)hipStreamSynchronize(h->s);
+  free_n_buffers(h);
+  free_m_buffers(h);
+  (void)hipFree(h->scalars);
+  (void)hipFree(h->info);
+  (void)hipFree(h->gout);
+  (void)hipFree(h->devP);
+  if (h->hostP) (void)hipHostFree(h->hostP);
+  if (h->hscal) (void)hipHostFree(h->hscal);
+  for (auto e : h->prof.pool) (void)hipEventDestroy(e);
+  if (h->s) (void)hipStreamDestroy(h->s);
+  delete h;
+}
+
+extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out) {
+  if (!out) return GOGP_EARG;
+  *out = nullptr;
+  if (gogp_desc_check(desc) != GOGP_OK) {
+    g_create_error = "invalid kernel descriptor";
+    return GOGP_EARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device available (libgogp_hip has no CPU fallback)";
+    return GOGP_EHIP;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= ndev) {
+    g_create_error = "device index out of range";
+    return GOGP_EARG;
+  }
+  gogp_handle *h = new (std::nothrow) gogp_handle();
+  if (!h) return GOGP_ENOMEM;
+  h->desc = *desc;
+  h->device = device;
+  h->D = desc->ndim;
+  h->ns = desc->ntheta_simil;
+  h->nn = gogp_desc_ntheta_noise(desc);
+  h->P = h->ns + h->nn;
+  for (int t = 0; t < desc->nterms; ++t)
+    if (desc->terms[t].ard) h->ard_dims = desc->ndim;
+  h->theta_s.assign(h->ns, 0.0);  // gp/gp.go:50-56
+  h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
+  if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&h->devP, sizeof(DevParams));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&h->hostP, sizeof(DevParams), hipHostMallocDefault);
+  if (e == hipSuccess)
+    e = hipHostMalloc((void **)&h->hscal, (NACC + 16) * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
+    gogp_destroy(h);
+    return GOGP_EHIP;
+  }
+  *out = h;
+  return GOGP_OK;
+}
+
+// ---- data -------------------------------------------------------------------------------
+static int ensure_n(gogp_handle *h, int64_t n) {
+  const int64_t npad = n <= 0 ? 0 : ((n + PANEL - 1) / PANEL) * PANEL;
+  h->n = n;
+  h->npad = npad;
+  h->nblk = (int)(npad / TILE);
+  h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
+  if (npad > h->cap_npad) {
+    free_n_buffers(h);
+    const size_t nn = (size_t)npad * (size_t)npad * sizeof(double);
+    HIPCHK(h, hipMalloc(&h->dX, (size_t)npad * h->D * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->bufA, nn));
+    HIPCHK(h, hipMalloc(&h->bufL, nn));
+    HIPCHK(h, hipMalloc(&h->Dinv, (size_t)(npad / TILE) * TILE * TILE * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->w, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->gpart, (size_t)grad_reduce_blocks(npad) * NACC * sizeof(double)));
+    h->cap_npad = npad;
+    // invalidate the produce workspace that depends on npad
+    free_m_buffers(h);
+  }
+  return GOGP_OK;
+}
+
+static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64_t n,
+                         hipMemcpyKind kind) {
+  if (!h) return GOGP_EARG;
+  if (n < 0 || (n > 0 && (!X || !y))) return fail(h, GOGP_EARG, "set_data: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_n(h, n);
+  if (rc != GOGP_OK) return rc;
+  h->have_data = true;
+  if (n == 0) return GOGP_OK;
+  // zero padding rows, then copy
+  HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)h->npad * h->D * sizeof(double), h->s));
+  HIPCHK(h, hipMemsetAsync(h->dy, 0, (size_t)h->npad * sizeof(double), h->s));
+  HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)n * h->D * sizeof(double), kind, h->s));
+  HIPCHK(h, hipMemcpyAsync(h->dy, y, (size_t)n * sizeof(double), kind, h->s));
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  return GOGP_OK;
+}
+
+extern "C" int gogp_set_data(gogp_handle *h, const double *X, const double *y, int64_t n) {
+  return set_data_impl(h, X, y, n, hipMemcpyHostToDevice);
+}
+
+extern "C" int gogp_set_data_device(gogp_handle *h, const double *dX, const double *dy,
+                                    int64_t n) {
+  return set_data_impl(h, dX, dy, n, hipMemcpyDeviceToDevice);
+}
+
+// ---- parameters ---------------------------------------------------------------------------
+static int upload_params(gogp_handle *h) {
+  DevParams &p = *h->hostP;
+  const gogp_desc &d = h->desc;
+  memset(&p, 0, sizeof p);
+  p.ndim = d.ndim;
+  p.nterms = d.nterms;
+  p.ns = h->ns;
+  p.nn = h->nn;
+  for (int t = 0; t < d.nterms; ++t) {
+    const gogp_term &T = d.terms[t];
+    p.kind[t] = T.kind;
+    p.ard[t] = T.ard;
+    p.c[t] = T.scale_idx >= 0 ? h->theta_s[T.scale_idx] : 1.0;
+    p.w[t] = 0.0;
+    if (T.kind == GOGP_K_PERIODIC)
+      p.w[t] = M_PI / (T.period_mult * h->theta_s[T.period_idx]);
+    for (int j = 0; j < d.ndim; ++j)
+      p.inv_len[t][j] = 1.0 / h->theta_s[T.len_idx + (T.ard ? j : 0)];
+  }
+  if (d.noise_kind == GOGP_NOISE_CONSTANT) {
+    p.noise_var = d.noise_std * d.noise_std;  // kernel/noise.go:27-30
+    p.dnoise = 0.0;
+  } else {
+    const double sd = h->theta_n[0];
+    p.noise_var = d.noise_scale * sd * sd;  // kernel/noise.go:47-49
+    p.dnoise = 2.0 * p.noise_var;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->devP, h->hostP, sizeof(DevParams), hipMemcpyHostToDevice, h->s));
+  return GOGP_OK;
+}
+
+// ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
+static int factorize(gogp_handle *h) {
+  const int64_t npad = h->npad, ld = npad;
+  hipStream_t s = h->s;
+  h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
+  h->notpd = -1;
+  int rc = upload_params(h);
+  if (rc != GOGP_OK) return rc;
+  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
+  launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
+  double *A = h->bufA, *L = h->bufL;
+  GemmProfile *pf = &h->prof;
+  const int npanel = (int)(npad / PANEL);
+  for (int p = 0; p < npanel; ++p) {
+    const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
+    double *D0 = h->Dinv + (size_t)(2 * p) * TILE * TILE;
+    double *D1 = D0 + TILE * TILE;
+    // first 128 columns of the panel
+    launch_diag128(s, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, D0, c0, h->n, h->info);
+    const int mt1 = (int)((npad - c1) / TILE);
+    // L[c1:, c0:c1] = A[c1:, c0:c1] * inv(L00)^T
+    launch_dgemm_nt(s, GEMM_RECT, mt1, 1, TILE, 1.0, A + c1 * ld + c0, ld, D0, TILE, 0.0,
+                    L + c1 * ld + c0, ld, pf);
+    // A[c1:, c1:c2] -= L[c1:, c0:c1] * L[c1:c2, c0:c1]^T
+    launch_dgemm_nt(s, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0, ld,
+                    1.0, A + c1 * ld + c1, ld, pf);
+    // second 128 columns
+    launch_diag128(s, A + c1 * ld + c1, ld, L + c1 * ld + c1, ld, D1, c1, h->n, h->info);
+    const int mt2 = (int)((npad - c2) / TILE);
+    if (mt2 > 0) {
+      launch_dgemm_nt(s, GEMM_RECT, mt2, 1, TILE, 1.0, A + c2 * ld + c1, ld, D1, TILE, 0.0,
+                      L + c2 * ld + c1, ld, pf);
+      // trailing update, rank 256, lower tiles only
+      launch_dgemm_nt(s, GEMM_LOWER, mt2, mt2, PANEL, -1.0, L + c2 * ld + c0, ld,
+                      L + c2 * ld + c0, ld, 1.0, A + c2 * ld + c2, ld, pf);
+    }
+  }
+  // forward substitution z = L^-1 y
+  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < h->nblk; ++b)
+    launch_trsv_fwd_step(s, L, ld, h->Dinv, b, h->nblk, h->w, h->z);
+  launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  long long info = 0;
+  memcpy(&info, h->hscal + 8, sizeof info);
+  if (info != 0) {
+    h->notpd = (int64_t)info - 1;
+    char buf[160];
+    snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)",
+             (long long)h->notpd);
+    h->err = buf;
+    return GOGP_ENOTPD;
+  }
+  const double logdet = h->hscal[0], ztz = h->hscal[1];
+  // gp/gp.go:244-253
+  h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
+  h->factored = true;
+  return GOGP_OK;
+}
+
+static int ensure_alpha(gogp_handle *h) {
+  if (h->have_alpha) return GOGP_OK;
+  if (!h->factored) return fail(h, GOGP_ESTATE, "no factorisation");
+  hipStream_t s = h->s;
+  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)h->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int b = h->nblk - 1; b >= 0; --b)
+    launch_trsv_bwd_step(s, h->bufL, h->npad, h->Dinv, b, h->nblk, h->w, h->alpha);
+  h->have_alpha = true;
+  return GOGP_OK;
+}
+
+static int set_theta_natural(gogp_handle *h, const double *ts, const double *tn) {
+  for (int i = 0; i < h->ns; ++i) {
+    if (!(ts[i] > 0.0) || !std::isfinite(ts[i]))
+      return fail(h, GOGP_EARG, "similarity parameters must be positive and finite");
+    h->theta_s[i] = ts[i];
+  }
+  for (int i = 0; i < h->nn; ++i) {
+    if (!std::isfinite(tn[i])) return fail(h, GOGP_EARG, "noise parameter must be finite");
+    h->theta_n[i] = tn[i];
+  }
+  return GOGP_OK;
+}
+
+extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
+                           const double *theta_noise) {
+  if (!h || !theta_simil || (h->nn > 0 && !theta_noise)) return fail(h, GOGP_EARG, "absorb: NULL");
+  if (!h->have_data) return fail(h, GOGP_ESTATE, "absorb: no data (gogp_set_data)");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = set_theta_natural(h, theta_simil, theta_noise);
+  if (rc != GOGP_OK) return rc;
+  h->observed = false;  // gp/gp.go:85-86: no gradient after Absorb
+  h->with_obs = false;
+  h->grad_valid = false;
+  if (h->n == 0) {  // gp/gp.go:101-104
+    h->lml = 0.0;
+    h->factored = false;
+    return GOGP_OK;
+  }
+  rc = factorize(h);
+  if (rc != GOGP_OK) return rc;
+  rc = ensure_alpha(h);  // gp/gp.go:232-236
+  if (rc != GOGP_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  return GOGP_OK;
+}
+
+static int observe_theta(gogp_handle *h, const double *x, double *lml) {
+  // gp/gp.go:378-385: theta = exp(x)
+  std::vector<double> th(h->P > 0 ? h->P : 1);
+  for (int i = 0; i < h->P; ++i) th[i] = exp(x[i]);
+  int rc = set_theta_natural(h, th.data(), th.data() + h->ns);
+  if (rc != GOGP_OK) return rc;
+  h->grad_valid = false;
+  if (h->n == 0) {
+    h->lml = 0.0;
+    h->factored = false;
+    h->observed = true;
+    if (lml) *lml = 0.0;
+    return GOGP_OK;
+  }
+  rc = factorize(h);  // gp/gp.go:402
+  if (rc != GOGP_OK) return rc;
+  h->observed = true;
+  if (lml) *lml = h->lml;  // gp/gp.go:412
+  return GOGP_OK;
+}
+
+extern "C" int gogp_observe(gogp_handle *h, const double *x, int64_t len, double *lml) {
+  if (!h || !x) return fail(h, GOGP_EARG, "observe: NULL");
+  if (len != h->P) return fail(h, GOGP_EARG, "len(x)");  // gp/gp.go:398-400
+  if (!h->have_data) return fail(h, GOGP_ESTATE, "observe: no data (gogp_set_data)");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->with_obs = false;
+  return observe_theta(h, x, lml);
+}
+
+extern "C" int gogp_observe_full(gogp_handle *h, const double *x, int64_t len, double *lml) {
+  if (!h || !x) return fail(h, GOGP_EARG, "observe: NULL");
+  if (len < h->P) return fail(h, GOGP_EARG, "len(x)");
+  const int64_t rest = len - h->P;
+  if (rest == 0) return gogp_observe(h, x, len, lml);
+  const int64_t n = rest / (h->D + 1);  // gp/gp.go:391
+  if (n * (h->D + 1) != rest) return fail(h, GOGP_EARG, "len(x)");  // gp/gp.go:398-400
+  int rc = gogp_set_data(h, x + h->P, x + h->P + n * h->D, n);
+  if (rc != GOGP_OK) return rc;
+  h->with_obs = true;
+  return observe_theta(h, x, lml);
+}
+
+extern "C" int gogp_lml(gogp_handle *h, double *lml) {
+  if (!h || !lml) return GOGP_EARG;
+  if (h->n == 0) {
+    *lml = 0.0;
+    return GOGP_OK;
+  }
+  if (!h->factored) return fail(h, GOGP_ESTATE, "LML: nothing absorbed");
+  *lml = h->lml;
+  return GOGP_OK;
+}
+
+// ---- gradient --------------------------------------------------------------------------------
+static int compute_kinv(gogp_handle *h) {
+  if (h->have_kinv) return GOGP_OK;
+  const int64_t npad = h->npad, ld = npad;
+  hipStream_t s = h->s;
+  if (!h->bufY)
+    HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
+  GemmProfile *pf = &h->prof;
+  launch_set_identity_blocks(s, R, ld, npad);
+  const int npanel = (int)(npad / PANEL);
+  for (int m = 0; m < npanel; ++m) {
+    const int64_t c0 = (int64_t)m * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
+    const double *D0 = h->Dinv + (size_t)(2 * m) * TILE * TILE;
+    const double *D1 = D0 + TILE * TILE;
+    const int mr = (int)(c2 / TILE);  // block rows 0 .. c2
+    // Y[0:c2, c0:c1] = R[0:c2, c0:c1] * inv(L00)^T
+    launch_dgemm_nt(s, GEMM_RECT, mr, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, Y + c0, ld, pf);
+    // R[0:c1, c1:c2] -= Y[0:c1, c0:c1] * L[c1:c2, c0:c1]^T
+    launch_dgemm_nt(s, GEMM_RECT, mr - 1, 1, TILE, -1.0, Y + c0, ld, L + c1 * ld + c0, ld, 1.0,
+                    R + c1, ld, pf);
+    // Y[0:c2, c1:c2] = R[0:c2, c1:c2] * inv(L11)^T
+    launch_dgemm_nt(s, GEMM_RECT, mr, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, Y + c1, ld, pf);
+    // R[0:c2, c2:] -= Y[0:c2, c0:c2] * L[c2:, c0:c2]^T
+    const int nt = (int)((npad - c2) / TILE);
+    if (nt > 0)
+      launch_dgemm_nt(s, GEMM_RECT, mr, nt, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
+                      R + c2, ld, pf);
+  }
+  // K^-1 (lower tiles) = Y Y^T, ragged K range; R is dead, write over it
+  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf);
+  h->have_kinv = true;
+  return GOGP_OK;
+}
+
+static int64_t grad_len(const gogp_handle *h) {
+  return h->with_obs ? h->P + h->n * (h->D + 1) : h->P;  // gp/gp.go:420-425
+}
+
+extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
+  if (!h || !grad) return fail(h, GOGP_EARG, "gradient: NULL");
+  if (!h->observed) return fail(h, GOGP_ESTATE, "Gradient before Observe");
+  if (len != grad_len(h)) return fail(h, GOGP_EARG, "gradient: wrong length");
+  for (int64_t i = 0; i < len; ++i) grad[i] = 0.0;
+  if (h->n == 0) return GOGP_OK;  // gp/gp.go:427-430
+  if (h->with_obs)
+    return fail(h, GOGP_EARG,
+                "gradient w.r.t. inputs/outputs (full Observe form) is not implemented on "
+                "the device path yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->grad_valid) {
+    int rc = compute_kinv(h);
+    if (rc != GOGP_OK) return rc;
+    rc = ensure_alpha(h);
+    if (rc != GOGP_OK) return rc;
+    hipStream_t s = h->s;
+    launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
+                       h->npad, h->gpart, h->gout);
+    HIPCHK(h, hipMemcpyAsync(h->hscal + 16, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    const double *a = h->hscal + 16;
+    h->grad_cache.assign(h->P, 0.0);
+    const gogp_desc &d = h->desc;
+    for (int t = 0; t < d.nterms; ++t) {
+      const gogp_term &T = d.terms[t];
+      if (T.scale_idx >= 0) h->grad_cache[T.scale_idx] += 0.5 * a[3 * t + 0];
+      if (T.ard) {
+        for (int j = 0; j < d.ndim; ++j) h->grad_cache[T.len_idx + j] += 0.5 * a[ACC_ARD0 + j];
+      } else {
+        h->grad_cache[T.len_idx] += 0.5 * a[3 * t + 1];
+      }
+      if (T.kind == GOGP_K_PERIODIC) h->grad_cache[T.period_idx] += 0.5 * a[3 * t + 2];
+    }
+    if (h->nn > 0) h->grad_cache[h->ns] = 0.5 * a[ACC_TRACE] * h->hostP->dnoise;
+    h->grad_valid = true;
+  }
+  for (int i = 0; i < h->P; ++i) grad[i] = h->grad_cache[i];
+  return GOGP_OK;
+}
+
+// ---- produce ----------------------------------------------------------------------------------
+static int ensure_m(gogp_handle *h, int64_t m, int64_t mpad) {
+  if (m > h->cap_m || mpad * h->npad > h->cap_mp_npad || !h->dZ) {
+    free_m_buffers(h);
+    HIPCHK(h, hipMalloc(&h->dZ, (size_t)std::max<int64_t>(m, 1) * h->D * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->pvec, (size_t)4 * std::max<int64_t>(mpad, 1) * sizeof(double)));
+    if (h->npad > 0) {
+      HIPCHK(h, hipMalloc(&h->KsT, (size_t)mpad * h->npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->Vt, (size_t)mpad * h->npad * sizeof(double)));
+    }
+    h->cap_m = m;
+    h->cap_mp_npad = mpad * h->npad;
+  }
+  return GOGP_OK;
+}
+
+extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *mu,
+                            double *sigma) {
+  if (!h || m < 0 || (m > 0 && (!Z || !mu || !sigma))) return fail(h, GOGP_EARG, "produce: NULL");
+  if (m == 0) return GOGP_OK;
+  if (h->n > 0 && !h->factored) return fail(h, GOGP_ESTATE, "Produce: nothing absorbed");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int64_t mpad = ((m + TILE - 1) / TILE) * TILE;
+  int rc = ensure_m(h, m, mpad);
+  if (rc != GOGP_OK) return rc;
+  hipStream_t s = h->s;
+  double *prior = h->pvec, *dmu = h->pvec + mpad, *dq = h->pvec + 2 * mpad,
+         *dsig = h->pvec + 3 * mpad;
+  if (h->n == 0 || !h->factored) {
+    // no observations: parameters may not have been uploaded yet
+    rc = upload_params(h);
+    if (rc != GOGP_OK) return rc;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->dZ, Z, (size_t)m * h->D * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_prior(s, h->devP, h->dZ, m, prior);  // gp/gp.go:269-278
+  if (h->n == 0) {                            // gp/gp.go:343-347
+    launch_sigma(s, prior, nullptr, m, dsig);
+    HIPCHK(h, hipMemcpyAsync(sigma, dsig, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int64_t j = 0; j < m; ++j) mu[j] = 0.0;
+    return GOGP_OK;
+  }
+  rc = ensure_alpha(h);
+  if (rc != GOGP_OK) return rc;
+  const int64_t npad = h->npad, ld = npad;
+  double *R = h->KsT, *V = h->Vt, *L = h->bufL;
+  launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, R, ld);  // gp/gp.go:322-332
+  // mean = Kstar^T alpha (gp/gp.go:335)
+  launch_rownorm_dot(s, R, ld, h->alpha, npad, m, dmu, nullptr);
+  // V^T = Kstar^T L^-T by blocked substitution on the GEMM kernel
+  GemmProfile *pf = nullptr;  // Produce launches are not part of the Observe+Gradient metric
+  const int mt = (int)(mpad / TILE);
+  const int npanel = (int)(npad / PANEL);
+  for (int p = 0; p < npanel; ++p) {
+    const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
+    const double *D0 = h->Dinv + (size_t)(2 * p) * TILE * TILE;
+    const double *D1 = D0 + TILE * TILE;
+    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, V + c0, ld, pf);
+    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, -1.0, V + c0, ld, L + c1 * ld + c0, ld, 1.0,
+                    R + c1, ld, pf);
+    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, V + c1, ld, pf);
+    const int nt = (int)((npad - c2) / TILE);
+    if (nt > 0)
+      launch_dgemm_nt(s, GEMM_RECT, mt, nt, PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld, 1.0,
+                      R + c2, ld, pf);
+  }
+  // (Kstar^T K^-1 Kstar)_jj = |V_j|^2 : only the diagonal of gp/gp.go:341-342 is read (:356)
+  launch_rownorm_dot(s, V, ld, nullptr, npad, m, nullptr, dq);
+  launch_sigma(s, prior, dq, m, dsig);
+  HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(sigma, dsig, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  return GOGP_OK;
+}
+
+// ---- cached state --------------------------------------------------------------------------------
+extern "C" int gogp_get_alpha(gogp_handle *h, double *alpha) {
+  if (!h || (h->n > 0 && !alpha)) return GOGP_EARG;
+  if (h->n == 0) return GOGP_OK;
+  if (!h->factored) return fail(h, GOGP_ESTATE, "Alpha: nothing absorbed");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_alpha(h);
+  if (rc != GOGP_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(alpha, h->alpha, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost, h->s));
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  return GOGP_OK;
+}
+
+extern "C" int gogp_get_factor(gogp_handle *h, double *Lout) {
+  if (!h || (h->n > 0 && !Lout)) return GOGP_EARG;
+  if (h->n == 0) return GOGP_OK;
+  if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
+  HIPCHK(h, hipSetDevice(h->device));
+  double *tmp = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, (size_t)h->n * h->n * sizeof(double)));
+  launch_extract_lower(h->s, h->bufL, h->npad, h->n, tmp);
+  hipError_t e = hipMemcpyAsync(Lout, tmp, (size_t)h->n * h->n * sizeof(double),
+                                hipMemcpyDeviceToHost, h->s);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->s);
+  (void)hipFree(tmp);
+  HIPCHK(h, e);
+  return GOGP_OK;
+}
+
+extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
+                               const double *theta_noise, const double *Lin,
+                               const double *alpha) {
+  if (!h || !theta_simil || (h->nn > 0 && !theta_noise)) return fail(h, GOGP_EARG, "set_factor: NULL");
+  if (!h->have_data) return fail(h, GOGP_ESTATE, "set_factor: no data");
+  if (h->n > 0 && (!Lin || !alpha)) return fail(h, GOGP_EARG, "set_factor: NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = set_theta_natural(h, theta_simil, theta_noise);
+  if (rc != GOGP_OK) return rc;
+  h->observed = false;
+  h->grad_valid = false;
+  h->have_kinv = false;
+  if (h->n == 0) return GOGP_OK;
+  rc = upload_params(h);
+  if (rc != GOGP_OK) return rc;
+  hipStream_t s = h->s;
+  const int64_t n = h->n, npad = h->npad;
+  double *tmp = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, (size_t)n * n * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(tmp, Lin, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    launch_pack_lower(s, tmp, n, npad, h->bufL, npad);
+    for (int b = 0; b < h->nblk; ++b)
+      launch_diag128_inv_only(s, h->bufL + (size_t)b * TILE * npad + (size_t)b * TILE, npad,
+                              h->Dinv + (size_t)b * TILE * TILE);
+    e = hipMemsetAsync(h->alpha, 0, (size_t)npad * sizeof(double), s);
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h->alpha, alpha, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
+  // z = L^T alpha is not needed: Produce uses alpha for the mean
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  HIPCHK(h, e);
+  h->factored = true;
+  h->have_alpha = true;
+  // LML of the restored state: -n/2 log 2pi - sum log L_ii - 1/2 y^T alpha
+  launch_lml_scalars(s, h->bufL, npad, h->alpha, h->dy, h->alpha, n, h->scalars);
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  h->lml = -0.5 * (double)n * log(2 * M_PI) - 0.5 * h->hscal[0] - 0.5 * h->hscal[2];
+  return GOGP_OK;
+}
+
+// ---- measurement hooks -----------------------------------------------------------------------------
+extern "C" int gogp_profile_enable(gogp_handle *h, int on) {
+  if (!h) return GOGP_EARG;
+  h->prof.on = on != 0;
+  h->prof.used = 0;
+  h->prof.flops = 0;
+  h->prof.launches = 0;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
+                                 double *gemm_flops) {
+  if (!h) return GOGP_EARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, h->prof.pool[i], h->prof.pool[i + 1]) == hipSuccess) ms += t;
+  }
+  if (gemm_ms) *gemm_ms = ms;
+  if (gemm_launches) *gemm_launches = h->prof.launches;
+  if (gemm_flops) *gemm_flops = h->prof.flops;
+  h->prof.used = 0;
+  h->prof.flops = 0;
+  h->prof.launches = 0;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) {
+  (void)value;
+  if (!h || !name) return GOGP_EARG;
+  return fail(h, GOGP_EARG, "unknown option");
+}
+
+extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops) {
+  if (!tflops || iters <= 0) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  return mfma_f64_peak(iters, tflops);
+}
+
+extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
+                                  const double *A, const double *B, double beta, double *C) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GOGP_EARG;
+  if (M % TILE || N % TILE || K % GEMM_BK) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipError_t e = hipMalloc(&dA, (size_t)M * K * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * K * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(dA, A, (size_t)M * K * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dB, B, (size_t)N * K * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)M * N * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_dgemm_nt(0, GEMM_RECT, (int)(M / TILE), (int)(N / TILE), K, alpha, dA, K, dB, K, beta,
+                    dC, N, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}

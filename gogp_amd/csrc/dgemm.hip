@@ -1,0 +1,292 @@
+// dgemm.hip -- the dominant kernel: fp64 NT GEMM/SYRK tile kernel on
+// v_mfma_f64_16x16x4_f64 (gfx950).
+//
+//   C(128x128 tile) = beta*C + alpha * A(128xK) * B(128xK)^T      (row-major)
+//
+// One kernel shape serves every O(N^3) step of the hot path:
+//   Cholesky trailing update   A22 -= L21 L21^T        GEMM_LOWER, A == B
+//   panel TRSM via the inverse L21  = A21 inv(L11)^T   GEMM_RECT
+//   triangular inverse (Y=L^-T) R  -= Y_m L_m^T        GEMM_RECT
+//   K^-1 = Y Y^T               ragged K range per tile GEMM_LAUUM
+//   Produce: V^T solve         same two RECT forms
+//
+// Reference counterpart: gonum's Dpotrf/Dpotri/Dtrsm/Dgemm behind
+// mat.Cholesky.Factorize / SolveTo (call sites gp/gp.go:228,338,454,480).
+//
+// Structure (CDNA4): 256 threads = 4 waves, each wave owns a 64x64 sub-tile as
+// 4x4 MFMA 16x16 accumulators (128 acc VGPRs).  K is walked in steps of 16:
+// both operand tiles (128 rows x 16 doubles = one 128-B line per row) are
+// staged global -> registers -> LDS, double-buffered, one barrier per step.
+// LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so
+// that the MFMA fragment reads (16 rows x 2 k per 32-lane group, ds_read_b64)
+// hit 32 distinct 8-B bank pairs: conflict-free.
+#include "common.h"
+
+namespace gogp {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const double *A;
+  const double *B;
+  double *C;
+  long lda, ldb, ldc;
+  int mt, nt;
+  int nkt;  // K / 16
+  double alpha, beta;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  // doubles; chunk = 16-B chunk index 0..7 within the 128-B row
+  return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE * GEMM_BK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+
+  // ---- tile assignment ----------------------------------------------------
+  int t = blockIdx.x;
+  if (MODE != GEMM_LAUUM) {
+    // XCD-aware remap (blocks b and b+8 share an XCD/L2): give each XCD a
+    // contiguous chunk of the tile list; bijective for any grid size.
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = t & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+  }
+  int ti, tj;
+  if (MODE == GEMM_RECT) {
+    ti = t / g.nt;
+    tj = t - ti * g.nt;
+  } else {
+    ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  }
+  const int kbeg = (MODE == GEMM_LAUUM) ? ti * TILE : 0;
+  const int nkt = g.nkt - kbeg / GEMM_BK;
+
+  const double *Ag = g.A + (long)ti * TILE * g.lda + kbeg;
+  const double *Bg = g.B + (long)tj * TILE * g.ldb + kbeg;
+
+  // ---- staging map: thread -> (row, 16-B chunk), 4 rows per operand --------
+  const int srow = tid >> 3;  // 0..31, +32*q
+  const int schunk = tid & 7;
+  const double *Ap = Ag + (long)srow * g.lda + schunk * 2;
+  const double *Bp = Bg + (long)srow * g.ldb + schunk * 2;
+  const long a_step = 32 * g.lda, b_step = 32 * g.ldb;
+  int soff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) soff[q] = lds_off(srow + 32 * q, schunk);
+
+  // ---- fragment map --------------------------------------------------------
+  const int wr = wid >> 1, wc = wid & 1;
+  const int frow = lane & 15;
+  const int fk = lane >> 4;      // k within an MFMA step: 0..3
+  const int fchunk = fk >> 1;    // + 2*kk
+  const int fhalf = fk & 1;
+  int arow[4], brow[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    arow[m] = wr * 64 + m * 16 + frow;
+    brow[m] = wc * 64 + m * 16 + frow;
+  }
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  f64x2 ra[4], rb[4];
+  // prologue: tile 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
+    rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    *reinterpret_cast<f64x2 *>(&lds[0][0][soff[q]]) = ra[q];
+    *reinterpret_cast<f64x2 *>(&lds[0][1][soff[q]]) = rb[q];
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      const double *ap = Ap + (long)(kt + 1) * GEMM_BK;
+      const double *bp = Bp + (long)(kt + 1) * GEMM_BK;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ra[q] = *reinterpret_cast<const f64x2 *>(ap + q * a_step);
+        rb[q] = *reinterpret_cast<const f64x2 *>(bp + q * b_step);
+      }
+    }
+    const double *la = lds[cur][0];
+    const double *lb = lds[cur][1];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a[m] = la[lds_off(arow[m], kk * 2 + fchunk) + fhalf];
+        b[m] = lb[lds_off(brow[m], kk * 2 + fchunk) + fhalf];
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][0][soff[q]]) = ra[q];
+        *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][1][soff[q]]) = rb[q];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: C/D fragment of v_mfma_f64_16x16x4_f64:
+  //      col = lane & 15, row = (lane >> 4) + 4 * reg
+  double *Cg = g.C + (long)(ti * TILE + wr * 64) * g.ldc + tj * TILE + wc * 64;
+  const int ccol = lane & 15;
+  const int crow = lane >> 4;
+  const double alpha = g.alpha, beta = g.beta;
+  if (beta != 0.0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
+          *p = alpha * acc[m][n][v] + beta * (*p);
+        }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
+          *p = alpha * acc[m][n][v];
+        }
+  }
+}
+
+void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
+                     const double *A, int64_t lda, const double *B, int64_t ldb,
+                     double beta, double *C, int64_t ldc, GemmProfile *prof) {
+  if (mt <= 0 || nt <= 0 || K <= 0) return;
+  GemmArgs g;
+  g.A = A;
+  g.B = B;
+  g.C = C;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.mt = mt;
+  g.nt = nt;
+  g.nkt = (int)(K / GEMM_BK);
+  g.alpha = alpha;
+  g.beta = beta;
+  int ntiles;
+  double flops;
+  if (mode == GEMM_RECT) {
+    ntiles = mt * nt;
+    flops = 2.0 * (double)mt * TILE * (double)nt * TILE * (double)K;
+  } else {
+    ntiles = mt * (mt + 1) / 2;
+    if (mode == GEMM_LOWER) {
+      flops = 2.0 * (double)ntiles * TILE * TILE * (double)K;
+    } else {
+      flops = 0;
+      for (int i = 0; i < mt; ++i)
+        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - (int64_t)i * TILE);
+    }
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof && prof->on) {
+    if (prof->used + 2 > prof->pool.size()) {
+      size_t old = prof->pool.size();
+      prof->pool.resize(old + 1024);
+      for (size_t i = old; i < prof->pool.size(); ++i) (void)hipEventCreate(&prof->pool[i]);
+    }
+    e0 = prof->pool[prof->used++];
+    e1 = prof->pool[prof->used++];
+    prof->flops += flops;
+    prof->launches += 1;
+    (void)hipEventRecord(e0, s);
+  }
+  dim3 grid(ntiles), block(256);
+  switch (mode) {
+    case GEMM_RECT:
+      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_RECT>, grid, block, 0, s, g);
+      break;
+    case GEMM_LOWER:
+      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_LOWER>, grid, block, 0, s, g);
+      break;
+    case GEMM_LAUUM:
+      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_LAUUM>, grid, block, 0, s, g);
+      break;
+  }
+  if (e1) (void)hipEventRecord(e1, s);
+}
+
+// ---- fp64 MFMA issue-rate microbenchmark (roofline calibration) -------------
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *sink) {
+  f64x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;  // keep the chain live
+}
+
+int mfma_f64_peak(int iters, double *tflops) {
+  double *sink = nullptr;
+  if (hipMalloc(&sink, 8) != hipSuccess) return GOGP_EHIP;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GOGP_EHIP;
+  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, 64, sink);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+  (void)hipEventRecord(e1, 0);
+  if (hipEventSynchronize(e1) != hipSuccess) return GOGP_EHIP;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  return GOGP_OK;
+}
+
+}  // namespace gogp

@@ -1,0 +1,138 @@
+// grad.hip -- fused hyperparameter-gradient reduction (HBM-read-bound).
+//
+// Reference: gp.GP.Gradient (gp/gp.go:418-499) forms, PER PARAMETER p, the dense
+// products r0 = (alpha alpha^T) dK_p and r1 = K^-1 dK_p and takes
+// 1/2 tr(r0 - r1) (gp/gp.go:476-485), with dK_p = theta_p dK/dtheta_p built per
+// pair by the AD tape during absorb (gp/gp.go:113-117,137-142).  Since
+// tr(M dK) = sum_ij M_ij dK_ij for symmetric matrices this equals
+//     grad_p = 1/2 sum_ij W_ij dK_p,ij ,   W = alpha alpha^T - K^-1,
+// which is what this kernel evaluates in ONE pass over the lower triangle of
+// K^-1, recomputing k(x_i,x_j) and its log-parameter derivatives on the fly
+// (no dK matrix is ever stored).  Off-diagonal elements count twice.
+//
+// Output: NACC slot sums (see common.h); the host maps slots to theta indices.
+#include "kern_eval.h"
+
+namespace gogp {
+
+constexpr int GR_BLOCKS_MAX = 2048;
+
+template <int ARD_D>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(
+    const DevParams *__restrict__ Pp, const double *__restrict__ X,
+    const double *__restrict__ alpha, const double *__restrict__ Kinv, long ld, long n, int nt,
+    int ntiles, double *__restrict__ partials) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Ri = sm;              // [64][D]
+  double *CjT = sm + 64 * D;    // [D][64]
+  double *ai = sm + 128 * D;    // [64]
+  double *aj = ai + 64;         // [64]
+  double *red = aj + 64;        // [4][NACC]
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+
+  double acc[ACC_TRACE + 1];
+#pragma unroll
+  for (int q = 0; q <= ACC_TRACE; ++q) acc[q] = 0.0;
+  double ard[ARD_D > 0 ? ARD_D : 1];
+#pragma unroll
+  for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) ard[q] = 0.0;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const long r0 = (long)ti * 64, c0 = (long)tj * 64;
+    __syncthreads();  // previous tile's readers are done
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int r = idx / D, d = idx - r * D;
+      Ri[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
+      CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+    }
+    if (tid < 64) ai[tid] = (r0 + tid < n) ? alpha[r0 + tid] : 0.0;
+    else if (tid < 128) aj[tid - 64] = (c0 + tid - 64 < n) ? alpha[c0 + tid - 64] : 0.0;
+    __syncthreads();
+    const long gj = c0 + tx;
+    const double *cj = CjT + tx;
+    const double ajv = aj[tx];
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = ty * 16 + rr;
+      const long gi = r0 + r;
+      if (gi < n && gj <= gi) {
+        const double w = ai[r] * ajv - Kinv[gi * ld + gj];
+        const double wgt = (gj < gi) ? 2.0 * w : w;
+        const double *ri = Ri + r * D;
+        simil_grad_accum<ARD_D>(
+            P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; }, wgt, acc, ard);
+        if (gi == gj) acc[ACC_TRACE] += w;
+      }
+    }
+  }
+
+  // ---- block reduction: wave shuffles, then 4 waves through LDS -------------
+  __syncthreads();
+  const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+  for (int q = 0; q <= ACC_TRACE; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wid * NACC + q] = v;
+  }
+  if (ARD_D > 0) {
+#pragma unroll
+    for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {
+      double v = ard[q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wid * NACC + ACC_ARD0 + q] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NACC) {
+    double v = 0.0;
+    const bool live = (tid <= ACC_TRACE) || (tid >= ACC_ARD0 && tid < ACC_ARD0 + ARD_D);
+    if (live) v = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+    partials[(long)blockIdx.x * NACC + tid] = v;
+  }
+}
+
+// out[q] = sum over blocks of partials[b][q], fixed order
+__global__ __launch_bounds__(128) void grad_final_kernel(const double *__restrict__ partials,
+                                                         int nblocks, double *__restrict__ out) {
+  const int q = threadIdx.x;
+  if (q >= NACC) return;
+  double v = 0.0;
+  for (int b = 0; b < nblocks; ++b) v += partials[(long)b * NACC + q];
+  out[q] = v;
+}
+
+int grad_reduce_blocks(int64_t npad) {
+  const int nt = (int)(npad / 64);
+  const long ntiles = (long)nt * (nt + 1) / 2;
+  return (int)(ntiles < GR_BLOCKS_MAX ? ntiles : GR_BLOCKS_MAX);
+}
+
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                        int64_t n, int64_t npad, double *partials, double *out) {
+  const int nt = (int)(npad / 64);
+  const int ntiles = nt * (nt + 1) / 2;
+  const int blocks = grad_reduce_blocks(npad);
+  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+#define GOGP_LAUNCH_GR(AD)                                                                      \
+  hipLaunchKernelGGL(grad_reduce_kernel<AD>, dim3(blocks), dim3(256), lds, s, p, X, alpha, Kinv, \
+                     (long)ld, (long)n, nt, ntiles, partials)
+  if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
+  else if (ard_dims <= 16) GOGP_LAUNCH_GR(16);
+  else if (ard_dims <= 32) GOGP_LAUNCH_GR(32);
+  else GOGP_LAUNCH_GR(64);
+#undef GOGP_LAUNCH_GR
+  hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(128), 0, s, partials, blocks, out);
+}
+
+}  // namespace gogp

@@ -1,0 +1,104 @@
+// gram.hip -- O(N^2) pairwise kernel evaluation (HBM-write-bound).
+//
+//   gram_kernel<false>: lower-triangular 64x64 tiles of
+//       K_ij = Simil(x_i, x_j) + [i==j] Noise          gp/gp.go:109-156,220-225
+//     (the reference walks j >= i and mirrors with SetSym; the blocked lower
+//      Cholesky that follows only reads the lower triangle, so only that is
+//      written).  Rows/columns >= n are padding: identity.
+//   gram_kernel<true>: cross-covariance for Produce, stored transposed,
+//       KsT[j][i] = Simil(x_i, z_j)                    gp/gp.go:322-332
+//   prior_kernel: k(z_j, z_j)                          gp/gp.go:269-278
+//
+// Layout: one workgroup = 64x64 tile, 256 threads.  The row inputs are staged
+// in LDS row-major (read as wave-uniform broadcasts), the column inputs
+// transposed [d][col] so that the 64 lanes of a wave read consecutive
+// addresses; each wave writes 512 contiguous bytes per output row.
+#include "kern_eval.h"
+
+namespace gogp {
+
+template <bool CROSS>
+__global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__ Pp,
+                                                   const double *__restrict__ Rsrc, long nrows,
+                                                   const double *__restrict__ Csrc, long ncols,
+                                                   double *__restrict__ Out, long ld, int ntc) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Ri = sm;            // [64][D]
+  double *CjT = sm + 64 * D;  // [D][64]
+  const int tid = threadIdx.x;
+  int ti, tj;
+  if (CROSS) {
+    ti = blockIdx.x / ntc;
+    tj = blockIdx.x - ti * ntc;
+  } else {
+    const int t = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  }
+  const long r0 = (long)ti * 64, c0 = (long)tj * 64;
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int r = idx / D, d = idx - r * D;
+    Ri[idx] = (r0 + r < nrows) ? Rsrc[(r0 + r) * D + d] : 0.0;
+    CjT[d * 64 + r] = (c0 + r < ncols) ? Csrc[(c0 + r) * D + d] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;
+  const long gj = c0 + tx;
+  const double *cj = CjT + tx;
+#pragma unroll 2
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = ty * 16 + rr;
+    const long gi = r0 + r;
+    const double *ri = Ri + r * D;
+    double k;
+    if (gi < nrows && gj < ncols) {
+      k = simil_value(
+          P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; });
+      if (!CROSS && gi == gj) k += P.noise_var;
+    } else {
+      k = (!CROSS && gi == gj) ? 1.0 : 0.0;
+    }
+    Out[gi * ld + gj] = k;
+  }
+}
+
+__global__ void prior_kernel(const DevParams *__restrict__ Pp, const double *__restrict__ Z,
+                             long m, double *__restrict__ prior) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const DevParams &P = *Pp;
+  const double *z = Z + j * P.ndim;
+  prior[j] = simil_value(
+      P, [&](int d) { return z[d]; }, [&](int d) { return z[d]; });
+}
+
+void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                       int64_t n, int64_t npad, double *K, int64_t ld) {
+  const int nt = (int)(npad / 64);
+  const int ntiles = nt * (nt + 1) / 2;
+  const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
+  hipLaunchKernelGGL(gram_kernel<false>, dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
+                     (long)n, K, (long)ld, nt);
+}
+
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT,
+                  int64_t ld) {
+  const int ntr = (int)(mpad / 64), ntc = (int)(npad / 64);
+  const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
+  hipLaunchKernelGGL(gram_kernel<true>, dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
+                     (long)n, KsT, (long)ld, ntc);
+}
+
+void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
+                  double *prior) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(prior_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, p, Z,
+                     (long)m, prior);
+}
+
+}  // namespace gogp

@@ -1,0 +1,259 @@
+// solve.hip -- O(N^2) bandwidth-bound pieces around the factor:
+//   blocked forward/backward substitution for alpha = K^-1 y
+//     (gonum Cholesky.SolveVecTo, call site gp/gp.go:232-236)
+//   log-determinant and y^T K^-1 y for LML (gp/gp.go:244-253)
+//   row norms / dots for Produce (gp/gp.go:335,341-342,356)
+//   small utilities (identity/zero fill for the triangular inverse, factor export)
+// All reductions are fixed-order (no atomics): results are bitwise reproducible.
+#include "common.h"
+
+namespace gogp {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// out[r] = sum_c M[r][c] * v[c]   (M 128x128 row-major with leading dim ldm),
+// computed by a 256-thread workgroup; v in LDS; result to LDS res[128].
+__device__ __forceinline__ void block_matvec(const double *__restrict__ M, long ldm,
+                                             const double *v, double *res) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // wave w handles rows w*32 .. w*32+31; 64 lanes cover the 128 columns
+  const double v0 = v[2 * lane], v1 = v[2 * lane + 1];
+  for (int r = wid * 32; r < wid * 32 + 32; ++r) {
+    const double2 m = *reinterpret_cast<const double2 *>(M + (long)r * ldm + 2 * lane);
+    double p = m.x * v0 + m.y * v1;
+    p = wave_sum(p);
+    if (lane == 0) res[r] = p;
+  }
+}
+
+// out[c] = sum_r M[r][c] * v[r]  (transposed product), 256 threads
+__device__ __forceinline__ void block_matvec_t(const double *__restrict__ M, long ldm,
+                                               const double *v, double *res, double *scratch) {
+  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  double p = 0.0;
+  for (int r = half * 64; r < half * 64 + 64; ++r) p += M[(long)r * ldm + c] * v[r];
+  if (half == 1) scratch[c] = p;
+  __syncthreads();
+  if (half == 0) res[c] = p + scratch[c];
+}
+
+// Forward step b: z_b = Dinv_b * w_b ; w_i -= L[i,b] z_b  (i > b).
+// grid = nblk - b workgroups; workgroup g handles block row i = b + g.
+__global__ __launch_bounds__(256) void trsv_fwd_kernel(const double *__restrict__ L, long ld,
+                                                       const double *__restrict__ Dinv, int b,
+                                                       double *__restrict__ w,
+                                                       double *__restrict__ z) {
+  __shared__ double vb[128], zb[128], upd[128];
+  const int tid = threadIdx.x;
+  const int i = b + blockIdx.x;
+  if (tid < 128) vb[tid] = w[(long)b * 128 + tid];
+  __syncthreads();
+  block_matvec(Dinv + (long)b * 128 * 128, 128, vb, zb);
+  __syncthreads();
+  if (i == b) {
+    if (tid < 128) z[(long)b * 128 + tid] = zb[tid];
+    return;
+  }
+  block_matvec(L + (long)i * 128 * ld + (long)b * 128, ld, zb, upd);
+  __syncthreads();
+  if (tid < 128) w[(long)i * 128 + tid] -= upd[tid];
+}
+
+// Backward step b: alpha_b = Dinv_b^T * w_b ; w_i -= L[b,i]^T alpha_b  (i < b).
+// grid = b + 1 workgroups; workgroup g handles block column i = g.
+__global__ __launch_bounds__(256) void trsv_bwd_kernel(const double *__restrict__ L, long ld,
+                                                       const double *__restrict__ Dinv, int b,
+                                                       double *__restrict__ w,
+                                                       double *__restrict__ alpha) {
+  __shared__ double vb[128], ab[128], upd[128], scratch[128];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x;
+  if (tid < 128) vb[tid] = w[(long)b * 128 + tid];
+  __syncthreads();
+  block_matvec_t(Dinv + (long)b * 128 * 128, 128, vb, ab, scratch);
+  __syncthreads();
+  if (i == b) {
+    if (tid < 128) alpha[(long)b * 128 + tid] = ab[tid];
+    return;
+  }
+  block_matvec_t(L + (long)b * 128 * ld + (long)i * 128, ld, ab, upd, scratch);
+  __syncthreads();
+  if (tid < 128) w[(long)i * 128 + tid] -= upd[tid];
+}
+
+void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
+                          int b, int nblk, double *w, double *z) {
+  hipLaunchKernelGGL(trsv_fwd_kernel, dim3(nblk - b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+                     z);
+}
+
+void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
+                          int b, int nblk, double *w, double *alpha) {
+  (void)nblk;
+  hipLaunchKernelGGL(trsv_bwd_kernel, dim3(b + 1), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+                     alpha);
+}
+
+// scalars[0] = sum_{i<n} 2 log L_ii ; scalars[1] = sum_{i<n} z_i^2 ;
+// scalars[2] = sum_{i<n} y_i alpha_i (only if alpha != nullptr)
+__global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restrict__ L, long ld,
+                                                           const double *__restrict__ z,
+                                                           const double *__restrict__ y,
+                                                           const double *__restrict__ alpha,
+                                                           long n, double *__restrict__ scalars) {
+  __shared__ double red[3][16];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    a += 2.0 * log(L[i * ld + i]);
+    const double zi = z[i];
+    b += zi * zi;
+    if (alpha) c += y[i] * alpha[i];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wid] = a;
+    red[1][wid] = b;
+    red[2][wid] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0, sc = 0;
+    for (int w = 0; w < 16; ++w) {
+      sa += red[0][w];
+      sb += red[1][w];
+      sc += red[2][w];
+    }
+    scalars[0] = sa;
+    scalars[1] = sb;
+    scalars[2] = sc;
+  }
+}
+
+void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
+                        const double *y, const double *alpha, int64_t n, double *scalars) {
+  hipLaunchKernelGGL(lml_scalars_kernel, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
+                     (long)n, scalars);
+}
+
+// one workgroup per row j < m: dot_j = sum_i V[j][i] vec[i], sq_j = sum_i V[j][i]^2
+__global__ __launch_bounds__(256) void rownorm_dot_kernel(const double *__restrict__ V, long ld,
+                                                          const double *__restrict__ vec,
+                                                          long ncols, double *__restrict__ dot,
+                                                          double *__restrict__ sq) {
+  __shared__ double red[2][4];
+  const long j = blockIdx.x;
+  const double *row = V + j * ld;
+  double a = 0.0, b = 0.0;
+  for (long i = threadIdx.x; i < ncols; i += 256) {
+    const double v = row[i];
+    if (vec) a += v * vec[i];
+    b += v * v;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wid] = a;
+    red[1][wid] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (dot) dot[j] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    if (sq) sq[j] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double *vec,
+                        int64_t ncols, int64_t m, double *dot, double *sq) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(rownorm_dot_kernel, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
+                     (long)ncols, dot, sq);
+}
+
+// R := upper block triangle (256-block rows) zero, identity on the diagonal.
+// One workgroup per 128-row x 1024-col strip keeps the stores full-line.
+__global__ __launch_bounds__(256) void identity_upper_kernel(double *__restrict__ R, long ld,
+                                                             long npad) {
+  const long row = blockIdx.y;
+  const long cstart = (row / PANEL) * PANEL;  // first column of this row's diagonal 256-block
+  const long c = cstart + ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= npad) return;
+  double2 v;
+  v.x = (c == row) ? 1.0 : 0.0;
+  v.y = (c + 1 == row) ? 1.0 : 0.0;
+  *reinterpret_cast<double2 *>(R + row * ld + c) = v;
+}
+
+void launch_set_identity_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
+  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)npad);
+  hipLaunchKernelGGL(identity_upper_kernel, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+}
+
+__global__ void fill_kernel(double *p, long count, double v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+void launch_fill(hipStream_t s, double *p, int64_t count, double v) {
+  if (count <= 0) return;
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, (long)count, v);
+}
+
+__global__ void extract_lower_kernel(const double *__restrict__ L, long ld, long n,
+                                     double *__restrict__ out) {
+  const long i = blockIdx.y;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  out[i * n + j] = (j <= i) ? L[i * ld + j] : 0.0;
+}
+
+void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n, double *out) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(extract_lower_kernel, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+}
+
+// pack a dense n x n lower factor into the padded buffer (identity padding)
+__global__ void pack_lower_kernel(const double *__restrict__ in, long n, long npad,
+                                  double *__restrict__ L, long ld) {
+  const long i = blockIdx.y;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  double v = 0.0;
+  if (i < n && j < n) v = (j <= i) ? in[i * n + j] : 0.0;
+  else if (i == j) v = 1.0;
+  L[i * ld + j] = v;
+}
+
+void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
+                       int64_t ld) {
+  dim3 grid((unsigned)((npad + 255) / 256), (unsigned)npad);
+  hipLaunchKernelGGL(pack_lower_kernel, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
+                     (long)ld);
+}
+
+// sigma_j = sqrt(prior_j - q_j), unclamped (gp/gp.go:356)
+__global__ void sigma_kernel(const double *__restrict__ prior, const double *__restrict__ q,
+                             long m, double *__restrict__ sigma) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) sigma[j] = sqrt(prior[j] - (q ? q[j] : 0.0));
+}
+
+void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,
+                  double *sigma) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(sigma_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, prior, q,
+                     (long)m, sigma);
+}
+
+}  // namespace gogp

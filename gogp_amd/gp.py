@@ -1,0 +1,290 @@
+"""Host-side mirror of the reference's ``gp`` package (gp/gp.go, gp/model.go)
+over the C ABI of include/gogp_hip.h.
+
+``GP`` keeps the reference's field and method names -- ``NDim, Simil, Noise,
+ThetaSimil, ThetaNoise, X, Y, Parallel`` and ``Absorb / LML / Produce / Observe
+/ Gradient`` (gp/gp.go:20-38,80,244,258,374,418) -- with the same argument
+meaning and the same error behaviour:
+
+  * ``Absorb`` returns normally or raises ``FactorizeError`` where the Go method
+    returns ``err`` (gp/gp.go:228-230);
+  * ``Observe`` raises where the reference panics (gp/gp.go:398-405);
+  * ``Produce`` returns ``(mu, sigma)`` or raises (gp/gp.go:338-340).
+
+All arithmetic runs on the GPU through libgogp_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .kernel import NoiseKernel, SimilKernel, build_desc
+
+
+class GogpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("gogp_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FactorizeError(GogpError):
+    """gp/gp.go:228-230: Factorize(K) failed, K is not positive definite."""
+
+    def __init__(self, msg: str, pivot: int):
+        super().__init__(_lib.GOGP_ENOTPD, msg)
+        self.pivot = pivot
+
+
+def _dp(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _arr(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class GP:
+    """Type GP is the barebone implementation of GP (gp/gp.go:19-38)."""
+
+    def __init__(self, NDim: int, Simil: SimilKernel, Noise: Optional[NoiseKernel] = None,
+                 ThetaSimil: Optional[Sequence[float]] = None,
+                 ThetaNoise: Optional[Sequence[float]] = None,
+                 X=None, Y=None, Parallel: bool = False, device: int = -1):
+        self.NDim = int(NDim)
+        self.Simil = Simil
+        self.Noise = Noise
+        # gp/gp.go:45-57 defaults(): Noise nil => ConstantNoise(1e-5) (done by
+        # build_desc); zero theta vectors when empty
+        self._desc = build_desc(self.NDim, Simil, Noise)
+        self._ns = Simil.NTheta()
+        self._nn = 1 if self._desc.noise_kind == 1 else 0
+        self.ThetaSimil: List[float] = list(ThetaSimil) if ThetaSimil is not None else [0.0] * self._ns
+        self.ThetaNoise: List[float] = list(ThetaNoise) if ThetaNoise is not None else [0.0] * self._nn
+        #: accepted for source compatibility; the device path is always parallel
+        self.Parallel = Parallel
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.gogp_create(ctypes.byref(self._desc), int(device), ctypes.byref(self._h))
+        if rc != _lib.GOGP_OK:
+            msg = L.gogp_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise GogpError(rc, msg)
+        self._X = np.zeros((0, self.NDim))
+        self._Y = np.zeros((0,))
+        self._data_dirty = True
+        self._with_obs = False
+        self._last_len = self._ns + self._nn
+        if X is not None:
+            self.X = X
+            self.Y = Y if Y is not None else []
+
+    # ---- plumbing ------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().gogp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == _lib.GOGP_OK:
+            return
+        L = _lib.lib()
+        msg = L.gogp_last_error(self._h).decode()
+        if rc == _lib.GOGP_ENOTPD:
+            raise FactorizeError(msg, int(L.gogp_notpd_index(self._h)))
+        raise GogpError(rc, msg)
+
+    # ---- data: gp.GP.X / gp.GP.Y (gp/gp.go:27-28) --------------------------------
+    @property
+    def X(self) -> np.ndarray:
+        return self._X
+
+    @X.setter
+    def X(self, x):
+        self._X = _arr(x).reshape(-1, self.NDim)
+        self._data_dirty = True
+
+    @property
+    def Y(self) -> np.ndarray:
+        return self._Y
+
+    @Y.setter
+    def Y(self, y):
+        self._Y = _arr(y).reshape(-1)
+        self._data_dirty = True
+
+    def _push_data(self):
+        if not self._data_dirty:
+            return
+        if len(self._X) != len(self._Y):
+            raise ValueError("len(X) != len(Y)")
+        self._check(_lib.lib().gogp_set_data(self._h, _dp(self._X), _dp(self._Y), len(self._Y)))
+        self._data_dirty = False
+
+    def set_data_device(self, dX_ptr: int, dy_ptr: int, n: int):
+        """Inputs already resident in HBM (device pointers, e.g. torch .data_ptr())."""
+        self._check(_lib.lib().gogp_set_data_device(self._h, ctypes.c_void_p(dX_ptr),
+                                                    ctypes.c_void_p(dy_ptr), int(n)))
+        self._data_dirty = False
+
+    # ---- gp.GP.Absorb (gp/gp.go:80-87) -----------------------------------------------
+    def Absorb(self, x, y) -> None:
+        """Absorb absorbs observations into the process.  Parameters are taken
+        from ThetaSimil / ThetaNoise (natural scale, gp/gp_test.go:29)."""
+        self.X, self.Y = x, y
+        self._push_data()
+        ts = _arr(self.ThetaSimil)
+        tn = _arr(self.ThetaNoise) if self._nn else np.zeros(1)
+        if ts.size != self._ns:
+            raise ValueError("len(ThetaSimil)")
+        self._with_obs = False
+        self._check(_lib.lib().gogp_absorb(self._h, _dp(ts), _dp(tn)))
+
+    # ---- gp.GP.LML (gp/gp.go:244-253) -----------------------------------------------
+    def LML(self) -> float:
+        v = ctypes.c_double(0.0)
+        self._check(_lib.lib().gogp_lml(self._h, ctypes.byref(v)))
+        return v.value
+
+    # ---- gp.GP.Produce (gp/gp.go:258-360) --------------------------------------------
+    def Produce(self, x):
+        z = _arr(x).reshape(-1, self.NDim)
+        m = len(z)
+        mu, sigma = np.zeros(m), np.zeros(m)
+        if m:
+            if self._data_dirty and len(self._Y) == 0:
+                self._push_data()
+            self._check(_lib.lib().gogp_produce(self._h, _dp(z), m, _dp(mu), _dp(sigma)))
+        return mu, sigma
+
+    # ---- gp.GP.Observe (gp/gp.go:374-413) ---------------------------------------------
+    def Observe(self, x) -> float:
+        """x = log-transformed hyperparameters [| inputs | outputs].  Raises where
+        the reference panics.  x itself is not modified (the reference's in-place
+        exp/log round trip, gp/gp.go:378-381,408-410, is not reproduced)."""
+        xa = _arr(x).reshape(-1)
+        P = self._ns + self._nn
+        if xa.size < P:
+            raise ValueError("len(x)")
+        lml = ctypes.c_double(0.0)
+        L = _lib.lib()
+        if xa.size == P:
+            self._push_data()
+            self._with_obs = False
+            rc = L.gogp_observe(self._h, _dp(xa), xa.size, ctypes.byref(lml))
+        else:
+            rest = xa.size - P
+            n = rest // (self.NDim + 1)
+            if n * (self.NDim + 1) != rest:
+                raise ValueError("len(x)")  # gp/gp.go:398-400 panic("len(x)")
+            rc = L.gogp_observe_full(self._h, _dp(xa), xa.size, ctypes.byref(lml))
+            if rc == _lib.GOGP_OK:
+                # gp/gp.go:391-396: X, Y are re-sliced from x
+                self._X = xa[P:P + n * self.NDim].reshape(n, self.NDim).copy()
+                self._Y = xa[P + n * self.NDim:].copy()
+                self._data_dirty = False
+                self._with_obs = True
+        self._check(rc)
+        theta = np.exp(xa[:P])
+        self.ThetaSimil = list(theta[:self._ns])  # gp/gp.go:384-385
+        self.ThetaNoise = list(theta[self._ns:])
+        self._last_len = xa.size
+        return lml.value
+
+    # ---- gp.GP.Gradient (gp/gp.go:418-499) ---------------------------------------------
+    def Gradient(self) -> np.ndarray:
+        g = np.zeros(self._last_len)
+        self._check(_lib.lib().gogp_gradient(self._h, _dp(g), g.size))
+        return g
+
+    # ---- cached computations: gp.GP.L, gp.GP.Alpha (gp/gp.go:34-37) ----------------------
+    @property
+    def Alpha(self) -> np.ndarray:
+        n = int(_lib.lib().gogp_n(self._h))
+        a = np.zeros(n)
+        if n:
+            self._check(_lib.lib().gogp_get_alpha(self._h, _dp(a)))
+        return a
+
+    @property
+    def L(self) -> np.ndarray:
+        """Lower Cholesky factor (gonum's mat.Cholesky holds U = L^T)."""
+        n = int(_lib.lib().gogp_n(self._h))
+        out = np.zeros((n, n))
+        if n:
+            self._check(_lib.lib().gogp_get_factor(self._h, _dp(out)))
+        return out
+
+    def restore(self, L, Alpha) -> None:
+        """Produce on stored results (gp/gp.go:255-257): re-install ThetaSimil,
+        ThetaNoise, X, L, Alpha without refactorising."""
+        self._push_data()
+        ts = _arr(self.ThetaSimil)
+        tn = _arr(self.ThetaNoise) if self._nn else np.zeros(1)
+        Lm, al = _arr(L), _arr(Alpha)
+        self._check(_lib.lib().gogp_set_factor(self._h, _dp(ts), _dp(tn), _dp(Lm), _dp(al)))
+
+    # ---- measurement hooks ----------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(_lib.lib().gogp_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, nl, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        self._check(_lib.lib().gogp_profile_read(self._h, ctypes.byref(ms), ctypes.byref(nl),
+                                                 ctypes.byref(fl)))
+        return ms.value, nl.value, fl.value
+
+
+class Model:
+    """gp.Model (gp/model.go:9-28): GP plus priors on the hyperparameters.
+    ``Priors`` is any object with Observe(x) -> float and Gradient() -> array."""
+
+    def __init__(self, gp: GP, Priors):
+        self.GP = gp
+        self.Priors = Priors
+        self._gGrad = None
+        self._pGrad = None
+
+    def Observe(self, x) -> float:
+        gll = self.GP.Observe(x)
+        self._gGrad = self.GP.Gradient()
+        pll = self.Priors.Observe(x)
+        self._pGrad = np.asarray(self.Priors.Gradient(), dtype=float)
+        return gll + pll
+
+    def Gradient(self) -> np.ndarray:
+        g = self._gGrad.copy()
+        g[:len(self._pGrad)] += self._pGrad
+        return g
+
+
+def mfma_f64_peak(iters: int = 20000, device: int = -1) -> float:
+    """fp64 MFMA issue-rate microbenchmark (TFLOP/s) used to calibrate the roofline."""
+    v = ctypes.c_double(0.0)
+    rc = _lib.lib().gogp_mfma_f64_peak(device, iters, ctypes.byref(v))
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "mfma_f64_peak")
+    return v.value
+
+
+def dgemm_nt_check(A: np.ndarray, B: np.ndarray, C: np.ndarray, alpha=1.0, beta=0.0,
+                  device: int = -1) -> np.ndarray:
+    """C = beta*C + alpha*A@B.T on the GPU tile kernel (test hook)."""
+    A, B = _arr(A), _arr(B)
+    out = _arr(C).copy()
+    M, K = A.shape
+    N = B.shape[0]
+    rc = _lib.lib().gogp_test_dgemm_nt(device, M, N, K, alpha, _dp(A), _dp(B), beta, _dp(out))
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "test_dgemm_nt")
+    return out

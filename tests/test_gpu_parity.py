@@ -1,0 +1,280 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called
+through the C ABI, against the CPU oracle and the reference's known answers.
+
+Tolerances: north_star asks LML / mu / sigma within 1e-6 relative (fp64); the
+reference's own tests use 1e-6 absolute (gp/gp_test.go:150,157,233) and 1e-4 for
+gradient components (gp/gp_test.go:170,248).  We test 1e-6 absolute on the
+known answers, <= 1e-8 relative on LML against the oracle, 1e-6 relative on
+mu/sigma and 1e-6 relative (scaled by the gradient norm) on the gradient.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gogp_amd import kernel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpmod():
+    from gogp_amd import gp
+    return gp
+
+
+def _noise(spec):
+    if spec["kind"] == "constant":
+        return kernel.ConstantNoise(spec["std"])
+    return kernel.UniformNoise
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    with open(os.path.join(golden_dir, "gp_test_known_answers.json")) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------------------
+# the tile kernel in isolation
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 128, 64), (128, 384, 272), (512, 512, 256)])
+def test_dgemm_tile_kernel(gpmod, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K))
+    B = rng.normal(size=(N, K))
+    C = rng.normal(size=(M, N))
+    got = gpmod.dgemm_nt_check(A, B, C, alpha=-1.0, beta=1.0)
+    want = C - A @ B.T
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * K)
+    got = gpmod.dgemm_nt_check(A, B, C, alpha=1.0, beta=0.0)
+    np.testing.assert_allclose(got, A @ B.T, rtol=0, atol=1e-12 * K)
+
+
+def test_dgemm_fragment_layout_asymmetric(gpmod):
+    """A = I against an asymmetric integer B catches a transposed C/D fragment
+    map (f64 MFMA uses row = (lane>>4) + 4*reg, not the f32 map)."""
+    M = N = K = 128
+    A = np.eye(M, K)
+    B = np.arange(N * K, dtype=float).reshape(N, K)  # B[n][k] = n*K + k
+    got = gpmod.dgemm_nt_check(A, B, np.zeros((M, N)))
+    np.testing.assert_array_equal(got, B.T)
+
+
+# ---------------------------------------------------------------------------
+# the reference's own known answers through the HIP path
+# ---------------------------------------------------------------------------
+def test_produce_known_answers(gpmod, known):
+    # gp/gp_test.go:133-162
+    for c in known["produce"]:
+        for parallel in (False, True):
+            g = gpmod.GP(1, kernel.Normal, _noise(c["noise"]), ThetaSimil=c["theta_simil"],
+                         Parallel=parallel)
+            g.Absorb(np.array(c["x"], dtype=float).reshape(-1, 1), c["y"])
+            mu, sigma = g.Produce(c["z"])
+            assert len(mu) == len(c["mu"]) and len(sigma) == len(c["sigma"])
+            for got, want in zip(mu, c["mu"]):
+                assert abs(got - want) <= 1e-6, (c["name"], mu)
+            for got, want in zip(sigma, c["sigma"]):
+                if math.isnan(got):  # the reference lets NaN pass
+                    assert want == 0
+                    continue
+                # sigma = sqrt(variance - covariance) with variance ~ covariance:
+                # sqrt amplifies 1e-16 rounding to 1e-8
+                assert abs(got - want) <= 1e-6, (c["name"], sigma)
+
+
+def test_elemental_model_known_answers(gpmod, known):
+    # gp/gp_test.go:231-267
+    from oracle.oracle import Oracle
+    for c in known["elemental"]:
+        x = np.array(c["x"], dtype=float)
+        g = gpmod.GP(1, kernel.Normal, _noise(c["noise"]))
+        ll = g.Observe(x)  # full form: inputs and outputs carried in x
+        assert abs(ll - c["ll"]) < 1e-6, c["name"]
+        P = g._ns + g._nn
+        n = (len(x) - P) // 2
+        # hyperparameters-only form (gp_test.go:254-267)
+        g2 = gpmod.GP(1, kernel.Normal, _noise(c["noise"]), X=x[P:P + n].reshape(-1, 1),
+                      Y=x[P + n:])
+        ll2 = g2.Observe(x[:P])
+        dll2 = g2.Gradient()
+        assert abs(ll2 - c["ll"]) < 1e-6
+        assert len(dll2) == P
+        o = Oracle(1, kernel.Normal, _noise(c["noise"]))
+        o.set_data(x[P:P + n].reshape(-1, 1), x[P + n:])
+        o.Observe(x[:P])
+        np.testing.assert_allclose(dll2, o.Gradient(), rtol=1e-8, atol=1e-10)
+
+
+# ---------------------------------------------------------------------------
+# HIP path vs oracle on seeded inputs
+# ---------------------------------------------------------------------------
+def _data(rng, n, D):
+    X = rng.uniform(0, 1, (n, D))
+    y = np.sin(2 * np.pi * X).sum(1) / np.sqrt(D) + 0.1 * rng.normal(size=n)
+    return X, (y - y.mean()) / y.std()
+
+
+CASES = [
+    ("normal1d", 1, kernel.Normal, kernel.ConstantNoise(0.1), [0.3], []),
+    ("scaled_rbf", 4, kernel.Scaled(kernel.Normal), kernel.UniformNoise, [1.0, 0.8], [0.1]),
+    ("ard_rbf", 5, kernel.Scaled(kernel.ARD(kernel.Normal, 5)), kernel.UniformNoise,
+     [1.2, 0.9, 1.0, 1.1, 1.2, 1.3], [0.2]),
+    ("matern32", 2, kernel.Scaled(kernel.Matern32), kernel.ScaledNoise(0.01), [1.0, 0.7], [1.5]),
+    ("matern52_ref", 3, kernel.Scaled(kernel.Matern52), kernel.UniformNoise, [0.9, 1.1], [0.15]),
+    ("matern52_textbook", 3, kernel.Scaled(kernel.Matern52Textbook), kernel.UniformNoise,
+     [0.9, 1.1], [0.15]),
+    ("periodic", 1, kernel.Scaled(kernel.Periodic), kernel.UniformNoise, [1.0, 0.8, 0.45], [0.2]),
+    ("hyperpriors", 1,
+     kernel.Sum([kernel.Scaled(kernel.Matern52), kernel.Scaled(kernel.PeriodScaled(kernel.Periodic, 10.0))],
+                order=[0, 2, 1, 3, 4]), kernel.ScaledNoise(0.01), [1.0, 0.5, 0.6, 1.3, 0.05], [2.0]),
+    ("default_noise", 2, kernel.Scaled(kernel.Matern32), None, [1.0, 0.3], []),
+]
+
+
+def _check_against(gpmod, oracle_cls, name, D, simil, noise, ts, tn, n, m, seed,
+                   lml_rtol=1e-8, grad_rtol=1e-6):
+    rng = np.random.default_rng(seed)
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(-0.1, 1.1, (m, D))
+    x = np.log(np.array(list(ts) + list(tn)))
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    o = oracle_cls(D, simil, noise)
+    o.set_data(X, y)
+    lml, lml_o = g.Observe(x), o.Observe(x)
+    assert abs(lml - lml_o) <= lml_rtol * max(1.0, abs(lml_o)), (name, lml, lml_o)
+    grad, grad_o = g.Gradient(), o.Gradient()
+    scale = max(1.0, np.abs(grad_o).max())
+    assert np.abs(grad - grad_o).max() <= grad_rtol * scale, (name, grad, grad_o)
+    mu, sigma = g.Produce(Z)
+    mu_o, sigma_o = o.Produce(Z)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8, err_msg=name)
+    np.testing.assert_allclose(sigma, sigma_o, rtol=1e-6, atol=1e-8, err_msg=name)
+    # cached state: gp.GP.Alpha / gp.GP.L (gp/gp.go:35-36)
+    alpha_o = o.Alpha
+    np.testing.assert_allclose(g.Alpha, alpha_o, rtol=1e-6, atol=1e-8 * np.abs(alpha_o).max())
+    return g, o
+
+
+@pytest.mark.parametrize("name,D,simil,noise,ts,tn", CASES, ids=[c[0] for c in CASES])
+def test_small_vs_faithful_oracle(gpmod, name, D, simil, noise, ts, tn):
+    from oracle.oracle import Oracle
+    g, o = _check_against(gpmod, Oracle, name, D, simil, noise, ts, tn, n=50, m=9, seed=7)
+    np.testing.assert_allclose(g.L, o.L, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 255, 256, 257, 700])
+def test_ragged_sizes(gpmod, n):
+    """Padding edges: N below / at / above the 128 tile and 256 panel sizes."""
+    from oracle.oracle import FastOracle
+    _check_against(gpmod, FastOracle, "n=%d" % n, 3, kernel.Scaled(kernel.Normal),
+                   kernel.UniformNoise, [1.0, 0.6], [0.2], n=n, m=5, seed=100 + n)
+
+
+@pytest.mark.parametrize("name,D,simil,noise,ts,tn", CASES[:6], ids=[c[0] for c in CASES[:6]])
+def test_mid_vs_fast_oracle(gpmod, name, D, simil, noise, ts, tn):
+    from oracle.oracle import FastOracle
+    _check_against(gpmod, FastOracle, name, D, simil, noise, ts, tn, n=1500, m=200, seed=11)
+
+
+def test_config2_n4096_d4(gpmod):
+    """BASELINE config 2: RBF + homoscedastic noise, N=4096, D=4, fp64."""
+    from oracle.oracle import FastOracle
+    D = 4
+    _check_against(gpmod, FastOracle, "config2", D, kernel.Scaled(kernel.Normal), kernel.UniformNoise,
+                   [1.0, math.sqrt(D / 6.0)], [0.1], n=4096, m=256, seed=20251115)
+
+
+def test_absorb_then_produce_and_restore(gpmod):
+    """Absorb (no gradient) -> Produce; then 'Produce on stored results'
+    (gp/gp.go:255-257) from exported L / Alpha."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(5)
+    D, n = 2, 300
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(0, 1, (33, D))
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    g = gpmod.GP(D, simil, noise, ThetaSimil=[1.1, 0.4], ThetaNoise=[0.2])
+    g.Absorb(X, y)
+    o = FastOracle(D, simil, noise)
+    o.Absorb(X, y, [1.1, 0.4], [0.2])
+    assert abs(g.LML() - o.LML()) <= 1e-8 * abs(o.LML())
+    mu, sigma = g.Produce(Z)
+    mu_o, sigma_o = o.Produce(Z)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sigma, sigma_o, rtol=1e-6, atol=1e-8)
+    with pytest.raises(gpmod.GogpError):
+        g.Gradient()  # no Observe: the reference has no dK after Absorb either
+    L, alpha = g.L, g.Alpha
+    g2 = gpmod.GP(D, simil, noise, ThetaSimil=[1.1, 0.4], ThetaNoise=[0.2], X=X, Y=y)
+    g2.restore(L, alpha)
+    mu2, sigma2 = g2.Produce(Z)
+    np.testing.assert_allclose(mu2, mu, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sigma2, sigma, rtol=1e-9, atol=1e-12)
+    assert abs(g2.LML() - g.LML()) <= 1e-9 * abs(g.LML())
+
+
+def test_not_positive_definite(gpmod):
+    """Duplicate inputs with zero noise: Factorize fails (gp/gp.go:228-230)."""
+    X = np.array([[0.0], [0.0], [1.0]])
+    y = np.array([1.0, 1.0, 0.0])
+    g = gpmod.GP(1, kernel.Normal, kernel.ConstantNoise(0.0), ThetaSimil=[1.0])
+    with pytest.raises(gpmod.FactorizeError) as ei:
+        g.Absorb(X, y)
+    assert ei.value.pivot == 1
+    with pytest.raises(gpmod.FactorizeError):
+        g.Observe(np.array([0.0]))
+
+
+def test_no_observations(gpmod):
+    """gp/gp.go:101-104,343-347,427-430."""
+    g = gpmod.GP(2, kernel.Scaled(kernel.Normal), kernel.UniformNoise)
+    g.X, g.Y = np.zeros((0, 2)), np.zeros(0)
+    assert g.Observe(np.log([2.0, 1.0, 0.1])) == 0.0
+    np.testing.assert_array_equal(g.Gradient(), np.zeros(3))
+    mu, sigma = g.Produce([[0.1, 0.2], [0.5, 0.5]])
+    np.testing.assert_array_equal(mu, np.zeros(2))
+    np.testing.assert_allclose(sigma, np.sqrt([2.0, 2.0]), rtol=1e-15)
+
+
+def test_observe_len_x(gpmod):
+    g = gpmod.GP(2, kernel.Normal, kernel.ConstantNoise(0.1))
+    with pytest.raises(ValueError):
+        g.Observe(np.zeros(1 + 4))  # gp/gp.go:398-400
+
+
+def test_repeated_observe_changes_theta(gpmod):
+    """Every Observe re-runs the whole path (no stale caches across calls)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(2)
+    D, n = 3, 400
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    o = FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    for k in range(4):
+        x = np.log([1.0 + 0.1 * k, 0.7 - 0.05 * k, 0.1 + 0.02 * k])
+        lml, lml_o = g.Observe(x), o.Observe(x)
+        assert abs(lml - lml_o) <= 1e-8 * abs(lml_o)
+        if k % 2 == 0:
+            go = o.Gradient()
+            assert np.abs(g.Gradient() - go).max() <= 1e-6 * max(1, np.abs(go).max())
+
+
+def test_barebones_csv_config1(gpmod, golden_dir):
+    """BASELINE config 1: tutorial/data/barebones.csv, c*Matern32 + 0.01*UniformNoise."""
+    from oracle.oracle import Oracle
+    data = np.loadtxt(os.path.join(golden_dir, "barebones.csv"), delimiter=",")
+    X, y = data[:, :1], data[:, 1]
+    y = (y - y.mean()) / y.std()
+    simil, noise = kernel.Scaled(kernel.Matern32), kernel.ScaledNoise(0.01)
+    g = gpmod.GP(1, simil, noise, X=X, Y=y)
+    o = Oracle(1, simil, noise)
+    o.set_data(X, y)
+    x = np.zeros(3)
+    assert abs(g.Observe(x) - o.Observe(x)) < 1e-9
+    np.testing.assert_allclose(g.Gradient(), o.Gradient(), rtol=1e-8, atol=1e-9)
