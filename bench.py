@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: GP.Observe + GP.Gradient evaluations per second.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one hyperparameters-only Observe(log theta) (Gram build + blocked
+fp64 Cholesky + forward solve + LML) followed by Gradient() (triangular inverse,
+K^-1, fused gradient reduction), theta changing every step.  X, y are resident
+in HBM before the timed region starts.  Workload: BASELINE.json configs[2]
+(RBF + white noise, N=16384, D=8, fp64, one MI355X).
+
+N > 1 in this round: every GPU evaluates its own hyperparameter candidate on
+the full data (the optimiser's multi-start / line-search candidates) -- weak
+scaling, no data-path collective; DESIGN.md "Multi-GPU" explains what comes next.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  "roofline":     the dominant kernel (fp64 MFMA GEMM/SYRK tile kernel), HIP-event
+                  timed on the stream it is launched on during the timed region;
+  "cpu_baseline": the CPU oracle's numpy/scipy twin ("port") on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6  # AMD public spec, fp64 matrix = vector
+
+
+def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
+    """Time the oracle's numpy/scipy twin on the first `sample_n` rows of the same
+    workload; returns the cpu_baseline object and the LML relative error of the
+    GPU path on that same sample."""
+    from threadpoolctl import threadpool_info
+    from gogp_amd import kernel, synth
+    from oracle.oracle import FastOracle  # checker / baseline only
+    X, y = synth.make_inputs(N, D, seed)
+    Xs, ys = X[:sample_n], y[:sample_n]
+    o = FastOracle(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, block=2048)
+    o.set_data(Xs, ys)
+    x = synth.log_theta_cycle(D, 0)
+    t0 = time.time()
+    lml = o.Observe(x)
+    g = o.Gradient()
+    dt = time.time() - t0
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    scale = (sample_n / float(N)) ** 3
+    out = {
+        "value": (1.0 / dt) * scale,
+        "unit": "evals/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": "1 Observe+Gradient at N=%d D=%d (first rows of the same inputs), %.1f s of "
+                  "scipy/OpenBLAS potrf+potri + numpy Gram/gradient; scaled by (%d/%d)^3 to N=%d"
+                  % (sample_n, D, dt, sample_n, N, N),
+        "measured_evals_per_s_at_sample": 1.0 / dt,
+    }
+    lml_gpu, g_gpu = lml_gpu_fn(Xs, ys, x)
+    rel = abs(lml_gpu - lml) / abs(lml)
+    grel = float(np.abs(g_gpu - g).max() / max(1.0, np.abs(g).max()))
+    return out, rel, grel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    from gogp_amd import dist as gd
+    from gogp_amd import kernel, synth
+    from gogp_amd import gp as G
+    gd.init("nccl", torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+
+    N, D = args.n, args.d
+    seed = 20251114 + 2  # seed = 20251114 + config index
+    X, y = synth.make_inputs(N, D, seed)
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    g = G.GP(D, simil, noise, device=local_rank)
+    # inputs resident in HBM before anything is timed
+    dX = torch.from_numpy(X).to("cuda")
+    dy = torch.from_numpy(y).to("cuda")
+    torch.cuda.synchronize()
+    g.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
+
+    def step(k):
+        lml = g.Observe(synth.log_theta_cycle(D, k, rank))
+        grad = g.Gradient()
+        return lml, grad
+
+    for k in range(args.warmup):
+        step(k)
+
+    def sync():
+        gd.barrier()
+        torch.cuda.synchronize()
+
+    g.profile_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        lml, grad = step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_launches, gemm_flops = g.profile_read()
+    g.profile_enable(False)
+    dt = gd.max_over_ranks(dt, device="cuda")
+
+    if rank == 0:
+        algo_flops_step = float(N) ** 3  # N^3/3 Cholesky + 2N^3/3 inverse
+        achieved = algo_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        try:
+            peak_cal = G.mfma_f64_peak(20000, local_rank)
+        except Exception:
+            peak_cal = None
+        out = {
+            "metric": "GP.Observe+Gradient evals/sec (fp64) at N=%d D=%d" % (N, D),
+            "value": world * args.steps / dt,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: RBF + white noise, N=%d D=%d fp64, Observe+Gradient "
+                            "(hyperparameters-only form), theta perturbed every step" % (N, D),
+                "N": N, "D": D, "kernel": "c*RBF(l) + sigma^2 I", "P": 3,
+                "parallelism": "1 evaluation per GPU" if world == 1 else
+                               "replicas: %d independent evaluations (one candidate theta per GPU)" % world,
+            },
+            "lml": lml,
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gogp::dgemm_nt_kernel (v_mfma_f64_16x16x4_f64 GEMM/SYRK tile kernel)",
+                "achieved": achieved,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS,
+                "traffic": None,
+                "algorithmic_flops_per_step": algo_flops_step,
+                "launches_per_step": gemm_launches / max(1, args.steps),
+                "avg_launch_ms": gemm_ms / max(1, gemm_launches),
+                "kernel_ms_per_step": gemm_ms / max(1, args.steps),
+                "launched_flops_per_step": gemm_flops / max(1, args.steps),
+                "peak_calibrated_mfma_f64": peak_cal,
+                "note": "achieved = N^3 algorithmic flop per step / event-timed kernel time per step; "
+                        "peak = 78.6 TFLOP/s spec; peak_calibrated = sustained v_mfma_f64 issue-rate "
+                        "microbenchmark on this device",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            def lml_gpu_fn(Xs, ys, x):
+                g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank)
+                v = g2.Observe(x)
+                gr = g2.Gradient()
+                g2.close()
+                return v, gr
+            cb, rel, grel = cpu_baseline(N, D, seed, min(args.cpu_sample_n, N), lml_gpu_fn)
+            out["cpu_baseline"] = cb
+            out["lml_rel_err_vs_oracle"] = rel
+            out["grad_rel_err_vs_oracle"] = grel
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -547,3 +547,63 @@ const double *gogp_oracle_dk(const gogp_oracle *o, int64_t p) {
 int64_t gogp_oracle_ndk(const gogp_oracle *o) { return o->ndk; }
 const double *gogp_oracle_theta_simil(const gogp_oracle *o) { return o->theta_s; }
 const double *gogp_oracle_theta_noise(const gogp_oracle *o) { return o->theta_n; }
+
+/* ---- multi-threaded O(N^2) pieces for the "fast" CPU path --------------------
+ * Same mathematics as absorb()/gradient above in the W-matrix form
+ *     grad_p = 1/2 sum_ij (alpha alpha^T - K^-1)_ij * theta_p dK_ij/dtheta_p ,
+ * used by oracle.FastOracle (with LAPACK potrf/potri for the O(N^3) parts) at
+ * sizes where the faithful per-parameter dense products (gp/gp.go:476-485) are
+ * out of reach, and as bench.py's cpu_baseline ("port").  OpenMP over rows. */
+
+/* K (n x n, full symmetric) = Simil(x_i,x_j) + [i==j] noise_var : gp/gp.go:109-156 */
+void gogp_oracle_gram_omp(const gogp_desc *d, const double *theta_s, double noise_var,
+                          const double *X, int64_t n, double *K) {
+  int D = d->ndim;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t i = 0; i < n; i++) {
+    for (int64_t j = 0; j <= i; j++) {
+      double k = gogp_oracle_simil(d, theta_s, X + i * D, X + j * D, NULL);
+      if (i == j) k += noise_var;
+      K[i * n + j] = k;
+      K[j * n + i] = k;
+    }
+  }
+}
+
+/* Kstar (n x m) = Simil(x_i, z_j) : gp/gp.go:322-332 */
+void gogp_oracle_cross_omp(const gogp_desc *d, const double *theta_s, const double *X,
+                           int64_t n, const double *Z, int64_t m, double *Ks) {
+  int D = d->ndim;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t j = 0; j < m; j++)
+      Ks[i * m + j] = gogp_oracle_simil(d, theta_s, X + i * D, Z + j * D, NULL);
+}
+
+/* out[p] (p < ntheta_simil) = 1/2 sum_ij W_ij theta_p dk_ij/dtheta_p,
+ * out[ntheta_simil] = trace(W);  W = alpha alpha^T - Kinv, Kinv read from its
+ * lower triangle (row-major n x n). */
+void gogp_oracle_grad_reduce_omp(const gogp_desc *d, const double *theta_s, const double *X,
+                                 const double *alpha, const double *Kinv, int64_t n,
+                                 double *out) {
+  int D = d->ndim, ns = d->ntheta_simil;
+  for (int p = 0; p <= ns; p++) out[p] = 0.0;
+#pragma omp parallel
+  {
+    double acc[GOGP_MAX_NDIM + 16];
+    double g[3 * GOGP_MAX_NDIM + 16];
+    for (int p = 0; p <= ns; p++) acc[p] = 0.0;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; i++) {
+      for (int64_t j = 0; j <= i; j++) {
+        double w = alpha[i] * alpha[j] - Kinv[i * n + j];
+        double wgt = (j < i) ? 2.0 * w : w;
+        gogp_oracle_simil(d, theta_s, X + i * D, X + j * D, g);
+        for (int p = 0; p < ns; p++) acc[p] += wgt * g[p] * theta_s[p];
+        if (i == j) acc[ns] += w;
+      }
+    }
+#pragma omp critical
+    for (int p = 0; p <= ns; p++) out[p] += (p < ns ? 0.5 : 1.0) * acc[p];
+  }
+}

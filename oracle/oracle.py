@@ -80,6 +80,13 @@ def lib():
         L.gogp_oracle_dk.argtypes = [ctypes.c_void_p, i64]
         L.gogp_oracle_ndk.restype = i64
         L.gogp_oracle_ndk.argtypes = [ctypes.c_void_p]
+        descp = ctypes.POINTER(CDesc)
+        L.gogp_oracle_gram_omp.restype = None
+        L.gogp_oracle_gram_omp.argtypes = [descp, dp, ctypes.c_double, dp, i64, dp]
+        L.gogp_oracle_cross_omp.restype = None
+        L.gogp_oracle_cross_omp.argtypes = [descp, dp, dp, i64, dp, i64, dp]
+        L.gogp_oracle_grad_reduce_omp.restype = None
+        L.gogp_oracle_grad_reduce_omp.argtypes = [descp, dp, dp, dp, dp, i64, dp]
         _lib = L
     return _lib
 
@@ -227,34 +234,50 @@ def gram_np(desc: CDesc, theta_s: np.ndarray, A: np.ndarray, B: np.ndarray,
             want_grad: bool = False):
     """Similarity matrix k(A_i, B_j) and (optionally) the list of
     theta_p * dk/dtheta_p matrices (derivative w.r.t. log theta_p), following
-    kernel/kernel.go with r^2 = sum_d ((a_d-b_d)/l_d)^2."""
+    kernel/kernel.go with r^2 = sum_d ((a_d-b_d)/l_d)^2.  Differences are formed
+    explicitly per dimension (no |a|^2+|b|^2-2ab cancellation)."""
     D = desc.ndim
     nA, nB = len(A), len(B)
     K = np.zeros((nA, nB))
     dK = [np.zeros((nA, nB)) for _ in range(desc.ntheta_simil)] if want_grad else None
-    diff = A[:, None, :] - B[None, :, :]  # nA x nB x D
+
+    def diff(j):
+        return A[:, j, None] - B[None, :, j]
+
     for T in _terms(desc):
         c = theta_s[T.scale_idx] if T.scale_idx >= 0 else 1.0
         ls = np.array([theta_s[T.len_idx + (j if T.ard else 0)] for j in range(D)])
         if T.kind == K_PERIODIC:
             p = T.period_mult * theta_s[T.period_idx]
-            phi = np.pi * np.abs(diff) / p
-            dd = np.sin(phi) / ls
-            s2 = (dd * dd).sum(-1)
+            s2 = np.zeros((nA, nB))
+            gp = np.zeros((nA, nB)) if want_grad else None
+            for j in range(D):
+                phi = (np.pi / p) * np.abs(diff(j))
+                dd = np.sin(phi) / ls[j]
+                s2 += dd * dd
+                if want_grad:
+                    gp += dd * np.cos(phi) * phi / ls[j]
             f = np.exp(-2 * s2)
             K += c * f
             if want_grad:
                 if T.scale_idx >= 0:
                     dK[T.scale_idx] += c * f
-                for j in range(D):
-                    li = T.len_idx + (j if T.ard else 0)
-                    dK[li] += c * f * 4 * dd[..., j] ** 2
-                    dK[T.period_idx] += c * f * 4 * dd[..., j] * np.cos(phi[..., j]) * phi[..., j] / ls[j]
+                dK[T.period_idx] += c * f * 4 * gp
+                if T.ard:
+                    for j in range(D):
+                        dd = np.sin((np.pi / p) * np.abs(diff(j))) / ls[j]
+                        dK[T.len_idx + j] += c * f * 4 * dd * dd
+                else:
+                    dK[T.len_idx] += c * f * 4 * s2
             continue
-        u = diff / ls
-        r2 = (u * u).sum(-1)
+        r2 = np.zeros((nA, nB))
+        for j in range(D):
+            u = diff(j)
+            u *= 1.0 / ls[j]
+            u *= u
+            r2 += u
         if T.kind == K_NORMAL:
-            f = np.exp(-r2 / 2)
+            f = np.exp(-0.5 * r2)
             dfdr2 = -0.5 * f
         else:
             r = np.sqrt(r2)
@@ -264,11 +287,11 @@ def gram_np(desc: CDesc, theta_s: np.ndarray, A: np.ndarray, B: np.ndarray,
                 dfdr2 = -1.5 * e
             elif T.kind == K_MATERN52:
                 e = np.exp(-SQRT5 * r)
-                f = (1 + SQRT5 * r + r * r) * e
+                f = (1 + SQRT5 * r + r2) * e
                 dfdr2 = -0.5 * (3 + SQRT5 * r) * e
             elif T.kind == K_MATERN52_TEXTBOOK:
                 e = np.exp(-SQRT5 * r)
-                f = (1 + SQRT5 * r + (5.0 / 3.0) * r * r) * e
+                f = (1 + SQRT5 * r + (5.0 / 3.0) * r2) * e
                 dfdr2 = -(5.0 / 6.0) * (1 + SQRT5 * r) * e
             else:
                 raise ValueError("kind")
@@ -278,23 +301,27 @@ def gram_np(desc: CDesc, theta_s: np.ndarray, A: np.ndarray, B: np.ndarray,
                 dK[T.scale_idx] += c * f
             if T.ard:
                 for j in range(D):
-                    dK[T.len_idx + j] += c * dfdr2 * (-2.0) * u[..., j] ** 2
+                    u = diff(j) / ls[j]
+                    dK[T.len_idx + j] += c * dfdr2 * (-2.0) * u * u
             else:
                 dK[T.len_idx] += c * dfdr2 * (-2.0) * r2
     return (K, dK) if want_grad else K
 
 
 class FastOracle:
-    """numpy/scipy restatement in the W-matrix form (hyperparameters-only
-    Observe/Gradient, Absorb, Produce).  Blocked so that N in the thousands
-    fits in memory: the gradient reduction streams row blocks."""
+    """Restatement in the W-matrix form (hyperparameters-only Observe/Gradient,
+    Absorb, Produce): LAPACK potrf/potri/potrs (scipy, OpenBLAS threads) for the
+    O(N^3) parts; the O(N^2) pair loops either in C/OpenMP (``use_c=True``, the
+    default: gogp_oracle_gram_omp / gogp_oracle_grad_reduce_omp) or in numpy
+    (``use_c=False``, kept as an independent cross-check)."""
 
-    def __init__(self, ndim: int, simil, noise=None, block: int = 1024):
+    def __init__(self, ndim: int, simil, noise=None, block: int = 1024, use_c: bool = True):
         self.desc = build_desc(ndim, simil, noise)
         self.ndim = ndim
         self.ns = self.desc.ntheta_simil
         self.nn = 1 if self.desc.noise_kind == NOISE_UNIFORM else 0
         self.block = block
+        self.use_c = use_c
         self.X = np.zeros((0, ndim))
         self.Y = np.zeros((0,))
         self.Lc = None
@@ -312,6 +339,10 @@ class FastOracle:
     def _gram(self, ts, tn):
         n = len(self.X)
         K = np.empty((n, n))
+        if self.use_c:
+            lib().gogp_oracle_gram_omp(ctypes.byref(self.desc), _dp(ts), float(self._noise_var(tn)),
+                                       _dp(self.X), n, _dp(K))
+            return K
         b = self.block
         for i0 in range(0, n, b):
             K[i0:i0 + b] = gram_np(self.desc, ts, self.X[i0:i0 + b], self.X)
@@ -358,19 +389,27 @@ class FastOracle:
         g = np.zeros(P)
         if n == 0:
             return g
-        # K^-1 from the factor (dpotri), full symmetric
+        # K^-1 from the factor (dpotri); the lower triangle is valid
         Kinv, info = sla.lapack.dpotri(self.Lc, lower=1, overwrite_c=0)
         assert info == 0
-        Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
-        a = self.Alpha
-        b = self.block
-        for i0 in range(0, n, b):
-            W = np.outer(a[i0:i0 + b], a) - Kinv[i0:i0 + b]
-            _, dK = gram_np(self.desc, self.ts, self.X[i0:i0 + b], self.X, want_grad=True)
-            for p in range(self.ns):
-                g[p] += 0.5 * float((W * dK[p]).sum())
-        if self.nn:
+        a = np.ascontiguousarray(self.Alpha)
+        if self.use_c:
+            Kinv = np.ascontiguousarray(Kinv)
+            out = np.zeros(self.ns + 1)
+            lib().gogp_oracle_grad_reduce_omp(ctypes.byref(self.desc), _dp(self.ts), _dp(self.X),
+                                              _dp(a), _dp(Kinv), n, _dp(out))
+            g[:self.ns] = out[:self.ns]
+            trW = out[self.ns]
+        else:
+            Kinv = np.tril(Kinv) + np.tril(Kinv, -1).T
+            b = self.block
+            for i0 in range(0, n, b):
+                W = np.outer(a[i0:i0 + b], a) - Kinv[i0:i0 + b]
+                _, dK = gram_np(self.desc, self.ts, self.X[i0:i0 + b], self.X, want_grad=True)
+                for p in range(self.ns):
+                    g[p] += 0.5 * float((W * dK[p]).sum())
             trW = float(a @ a) - float(np.trace(Kinv))
+        if self.nn:
             g[self.ns] = 0.5 * trW * 2.0 * self.desc.noise_scale * self.tn[0] ** 2
         return g
 
@@ -382,7 +421,12 @@ class FastOracle:
                           for i in range(m)]) if m else np.zeros(0)
         if len(self.X) == 0:
             return np.zeros(m), np.sqrt(prior)
-        Ks = gram_np(self.desc, self.ts, self.X, Z)  # n x m
+        if self.use_c:
+            Ks = np.empty((len(self.X), m))
+            lib().gogp_oracle_cross_omp(ctypes.byref(self.desc), _dp(self.ts), _dp(self.X),
+                                        len(self.X), _dp(Z), m, _dp(Ks))
+        else:
+            Ks = gram_np(self.desc, self.ts, self.X, Z)  # n x m
         mu = Ks.T @ self.Alpha
         v = sla.cho_solve((self.Lc, True), Ks, check_finite=False)
         cov = np.einsum("ij,ij->j", Ks, v)

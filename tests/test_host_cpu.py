@@ -1,0 +1,144 @@
+"""CPU-side tests (no GPU needed): the C-ABI library loads and exports every
+symbol include/gogp_hip.h declares, host logic (descriptors, synthetic inputs,
+rank plumbing), and the product path fails loudly without a HIP device."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gogp_amd import _lib, kernel, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "gogp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gogp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.gogp_version().decode().startswith("gogp_hip")
+
+
+def test_descriptor_struct_layout_matches_header(lib):
+    # a descriptor built in Python must validate in C: catches field-order drift
+    d = kernel.build_desc(3, kernel.Scaled(kernel.ARD(kernel.Normal, 3)), kernel.UniformNoise)
+    assert lib.gogp_desc_check(ctypes.byref(d)) == _lib.GOGP_OK
+    assert lib.gogp_desc_ntheta_noise(ctypes.byref(d)) == 1
+    d.terms[0].len_idx = 2  # 2 + ndim(3) > ntheta(4)
+    assert lib.gogp_desc_check(ctypes.byref(d)) == _lib.GOGP_EARG
+    d2 = kernel.build_desc(1, kernel.Periodic, None)
+    assert lib.gogp_desc_check(ctypes.byref(d2)) == _lib.GOGP_OK
+    assert lib.gogp_desc_ntheta_noise(ctypes.byref(d2)) == 0
+    assert abs(d2.noise_std - 1e-5) < 1e-20  # gp/gp.go:43-48 default
+    d2.terms[0].period_mult = 0.0
+    assert lib.gogp_desc_check(ctypes.byref(d2)) == _lib.GOGP_EARG
+    assert ctypes.sizeof(kernel.CTerm) == 32
+    assert ctypes.sizeof(kernel.CDesc) == 32 + 4 * 32
+
+
+def test_kernel_composition_layouts():
+    # tutorial/barebones/kernel/kernel.go:14-18: theta = [c, l]
+    k = kernel.Scaled(kernel.Matern32)
+    assert k.NTheta() == 2 and k.terms[0].scale_idx == 0 and k.terms[0].len_idx == 1
+    # tutorial/hyperpriors/kernel/kernel.go:12-25: theta = [c1, c2, l1, l2, p]
+    hp = kernel.Sum([kernel.Scaled(kernel.Matern52),
+                     kernel.Scaled(kernel.PeriodScaled(kernel.Periodic, 10.0))],
+                    order=[0, 2, 1, 3, 4])
+    assert hp.NTheta() == 5
+    t0, t1 = hp.terms
+    assert (t0.scale_idx, t0.len_idx) == (0, 2)
+    assert (t1.scale_idx, t1.len_idx, t1.period_idx, t1.period_mult) == (1, 3, 4, 10.0)
+    x = [1.3, 0.4, 0.9, 1.1, 0.07, 0.2, 1.5]
+    want = (x[0] * kernel.Matern52.Observe([x[2], x[5], x[6]])
+            + x[1] * kernel.Periodic.Observe([x[3], 10 * x[4], x[5], x[6]]))
+    assert abs(hp.Observe(x) - want) < 1e-15
+    with pytest.raises(TypeError):
+        kernel.build_desc(1, lambda x: 0.0, None)
+    # noise kernels: kernel/noise.go
+    assert kernel.ConstantNoise(0.1).Observe([0.0]) == pytest.approx(0.01)
+    assert kernel.UniformNoise.Observe([0.3, 7.0]) == pytest.approx(0.09)
+    assert kernel.ScaledNoise(0.01).Observe([2.0, 0.0]) == pytest.approx(0.04)
+
+
+def test_synthetic_inputs_are_reproducible():
+    X1, y1 = synth.make_inputs(1000, 8, 20251116)
+    X2, y2 = synth.make_inputs(1000, 8, 20251116)
+    assert np.array_equal(X1, X2) and np.array_equal(y1, y2)
+    assert 0.0 <= X1.min() and X1.max() < 1.0
+    assert abs(X1.mean() - 0.5) < 0.02 and abs(y1.std() - 1.0) < 1e-12
+    # prefix property: a counter-based stream gives the same first rows for any n
+    X3, _ = synth.make_inputs(10, 8, 20251116)
+    assert np.array_equal(X3, X1[:10])
+    ths = [tuple(synth.log_theta_cycle(8, k)) for k in range(6)]
+    assert all(ths[k] != ths[k + 1] for k in range(5))  # theta changes every step
+
+
+def test_no_gpu_fails_loudly(lib):
+    """No CPU fallback: without a HIP device gogp_create returns GOGP_EHIP and the
+    Python mirror raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from gogp_amd import gp
+    with pytest.raises(gp.GogpError) as ei:
+        gp.GP(1, kernel.Normal)
+    assert ei.value.code == _lib.GOGP_EHIP
+    v = ctypes.c_double()
+    assert lib.gogp_mfma_f64_peak(0, 10, ctypes.byref(v)) == _lib.GOGP_EHIP
+
+
+def test_product_does_not_import_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gogp_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+                assert "libgogp_oracle" not in src, fn
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from gogp_amd import dist as gd
+rank, world = gd.init("gloo")
+assert world == 2
+gd.barrier()
+assert gd.max_over_ranks(1.0 + rank) == 2.0
+ncand, width = 5, 4
+mine = gd.my_candidates(ncand, rank, world)
+vals = np.array([[i, 10.0 * i, rank, -i] for i in mine], dtype=float).reshape(len(mine), width)
+allv = gd.gather_results(mine, vals, ncand, width)
+for i in range(ncand):
+    assert allv[i, 0] == i and allv[i, 1] == 10.0 * i and allv[i, 2] == i %% world
+gd.barrier()
+dist.destroy_process_group()
+open(os.path.join(%(out)r, "rank%%d.ok" %% rank), "w").write("ok")
+"""
+
+
+def test_rank_plumbing_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()

@@ -147,19 +147,23 @@ def test_fast_oracle_matches_faithful(simil, ndim, ntheta):
     X = rng.uniform(0, 1, (n, ndim))
     y = np.sin(X.sum(1) * 3) + 0.1 * rng.normal(size=n)
     noise = kernel.ScaledNoise(0.5)
-    a, b = Oracle(ndim, simil, noise), FastOracle(ndim, simil, noise, block=16)
+    a = Oracle(ndim, simil, noise)
     assert simil.NTheta() == ntheta
     x = np.log(rng.uniform(0.5, 1.5, ntheta + 1))
     a.set_data(X, y)
-    b.set_data(X, y)
-    la, lb = a.Observe(x), b.Observe(x)
-    assert abs(la - lb) < 1e-9 * max(1, abs(la))
-    np.testing.assert_allclose(b.Gradient(), a.Gradient(), rtol=1e-8, atol=1e-9)
+    la = a.Observe(x)
+    ga = a.Gradient()
     Z = rng.uniform(0, 1, (7, ndim))
     ma, sa = a.Produce(Z)
-    mb, sb = b.Produce(Z)
-    np.testing.assert_allclose(mb, ma, rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(sb, sa, rtol=1e-7, atol=1e-9)
+    for use_c in (True, False):  # C/OpenMP pair loops and the independent numpy path
+        b = FastOracle(ndim, simil, noise, block=16, use_c=use_c)
+        b.set_data(X, y)
+        lb = b.Observe(x)
+        assert abs(la - lb) < 1e-9 * max(1, abs(la))
+        np.testing.assert_allclose(b.Gradient(), ga, rtol=1e-8, atol=1e-9)
+        mb, sb = b.Produce(Z)
+        np.testing.assert_allclose(mb, ma, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sb, sa, rtol=1e-7, atol=1e-9)
 
 
 def test_withobs_gradient_matches_fd():
