@@ -59,7 +59,7 @@ def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
         "cores": int(threads),
         "kind": "port",
         "sample": "1 Observe+Gradient at N=%d D=%d (first rows of the same inputs), %.1f s of "
-                  "scipy/OpenBLAS potrf+potri + numpy Gram/gradient; scaled by (%d/%d)^3 to N=%d"
+                  "scipy/OpenBLAS potrf+potri+potrs and C/OpenMP Gram + gradient pair loops; scaled by (%d/%d)^3 to N=%d"
                   % (sample_n, D, dt, sample_n, N, N),
         "measured_evals_per_s_at_sample": 1.0 / dt,
     }

@@ -19,6 +19,7 @@
 //   LAUUM (K^-1 = Y Y^T) -> backward solve (alpha) -> fused gradient reduce.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -52,7 +53,12 @@ struct gogp_handle {
   // produce workspace
   double *dZ = nullptr, *KsT = nullptr, *Vt = nullptr, *pvec = nullptr;
   int64_t cap_m = 0, cap_mp_npad = 0;
-  hipStream_t s = nullptr;
+  hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
+  hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
+                             // skinny updates, substitution steps -- overlaps the big updates
+  std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
+  int lookahead = 1;
+  bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
   // state
   std::vector<double> theta_s, theta_n;
   bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
@@ -162,6 +168,9 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hostP) (void)hipHostFree(h->hostP);
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
+  for (auto e : h->evs) (void)hipEventDestroy(e);
+  if (h->sp) (void)hipStreamSynchronize(h->sp);
+  if (h->sp) (void)hipStreamDestroy(h->sp);
   if (h->s) (void)hipStreamDestroy(h->s);
   delete h;
 }
@@ -198,7 +207,27 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   h->theta_s.assign(h->ns, 0.0);  // gp/gp.go:50-56
   h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    // The main stream may be kept off a few CUs so that the panel stream's
+    // single-workgroup diagonal kernels never queue behind trailing-update tiles.
+    const char *rs = getenv("GOGP_RESERVE_CUS");
+    const int reserve = rs ? atoi(rs) : 0;
+    hipDeviceProp_t prop;
+    if (reserve > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+        reserve < prop.multiProcessorCount) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+      e = hipExtStreamCreateWithCUMask(&h->s, (uint32_t)mask.size(), mask.data());
+    } else {
+      e = hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
+    }
+  }
+  if (e == hipSuccess) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
+  }
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
@@ -300,55 +329,99 @@ static int upload_params(gogp_handle *h) {
   return GOGP_OK;
 }
 
+// ---- cross-stream events -----------------------------------------------------------------
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_BASE = 4 };
+static hipEvent_t ev(gogp_handle *h, size_t i) {
+  while (h->evs.size() <= i) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    h->evs.push_back(e);
+  }
+  return h->evs[i];
+}
+// "a then b": work enqueued on `to` after this call waits for everything
+// enqueued on `from` before it
+static void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = ev(h, i);
+  (void)hipEventRecord(e, from);
+  (void)hipStreamWaitEvent(to, e, 0);
+}
+
 // ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
 static int factorize(gogp_handle *h) {
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
+  // without lookahead everything runs in order on the main stream
+  hipStream_t sp = h->lookahead ? h->sp : h->s;
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
+  h->alpha_pending = false;
   h->notpd = -1;
   int rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
   launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
+  order(h, EV_GRAM, s, sp);
   double *A = h->bufA, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
+  // working copy of y for the forward substitution (runs on the panel stream)
+  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
   for (int p = 0; p < npanel; ++p) {
     const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
     double *D0 = h->Dinv + (size_t)(2 * p) * TILE * TILE;
     double *D1 = D0 + TILE * TILE;
-    // first 128 columns of the panel
-    launch_diag128(s, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, D0, c0, h->n, h->info);
+    // ---- panel factorisation (panel stream) ---------------------------------------
+    launch_diag128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, D0, c0, h->n, h->info);
     const int mt1 = (int)((npad - c1) / TILE);
     // L[c1:, c0:c1] = A[c1:, c0:c1] * inv(L00)^T
-    launch_dgemm_nt(s, GEMM_RECT, mt1, 1, TILE, 1.0, A + c1 * ld + c0, ld, D0, TILE, 0.0,
+    launch_dgemm_nt(sp, GEMM_RECT, mt1, 1, TILE, 1.0, A + c1 * ld + c0, ld, D0, TILE, 0.0,
                     L + c1 * ld + c0, ld, pf);
     // A[c1:, c1:c2] -= L[c1:, c0:c1] * L[c1:c2, c0:c1]^T
-    launch_dgemm_nt(s, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0, ld,
-                    1.0, A + c1 * ld + c1, ld, pf);
-    // second 128 columns
-    launch_diag128(s, A + c1 * ld + c1, ld, L + c1 * ld + c1, ld, D1, c1, h->n, h->info);
+    launch_dgemm_nt(sp, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0,
+                    ld, 1.0, A + c1 * ld + c1, ld, pf);
+    launch_diag128(sp, A + c1 * ld + c1, ld, L + c1 * ld + c1, ld, D1, c1, h->n, h->info);
     const int mt2 = (int)((npad - c2) / TILE);
-    if (mt2 > 0) {
-      launch_dgemm_nt(s, GEMM_RECT, mt2, 1, TILE, 1.0, A + c2 * ld + c1, ld, D1, TILE, 0.0,
+    if (mt2 > 0)
+      launch_dgemm_nt(sp, GEMM_RECT, mt2, 1, TILE, 1.0, A + c2 * ld + c1, ld, D1, TILE, 0.0,
                       L + c2 * ld + c1, ld, pf);
-      // trailing update, rank 256, lower tiles only
-      launch_dgemm_nt(s, GEMM_LOWER, mt2, mt2, PANEL, -1.0, L + c2 * ld + c0, ld,
+    order(h, EV_BASE + 2 * p, sp, s);  // panel p of L is final
+    // forward substitution steps of this panel fill the panel stream's wait for
+    // the next block column
+    launch_trsv_fwd_step(sp, L, ld, h->Dinv, 2 * p, h->nblk, h->w, h->z);
+    launch_trsv_fwd_step(sp, L, ld, h->Dinv, 2 * p + 1, h->nblk, h->w, h->z);
+    // ---- trailing update, rank 256 (main stream) ------------------------------------
+    if (mt2 > 0) {
+      const int ntn = mt2 < 2 ? mt2 : 2;
+      // next block column first: A[c2:, c2:c2+256] -= L[c2:, c0:c2] * L[c2:c2+256, c0:c2]^T
+      launch_dgemm_nt(s, GEMM_RECT, mt2, ntn, PANEL, -1.0, L + c2 * ld + c0, ld,
                       L + c2 * ld + c0, ld, 1.0, A + c2 * ld + c2, ld, pf);
+      order(h, EV_BASE + 2 * p + 1, s, sp);  // next panel may start
+      // the rest of the trailing matrix, lower tiles only
+      if (mt2 > 2) {
+        const int64_t c3 = c2 + PANEL;
+        launch_dgemm_nt(s, GEMM_LOWER, mt2 - 2, mt2 - 2, PANEL, -1.0, L + c3 * ld + c0, ld,
+                        L + c3 * ld + c0, ld, 1.0, A + c3 * ld + c3, ld, pf);
+      }
     }
   }
-  // forward substitution z = L^-1 y
-  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int b = 0; b < h->nblk; ++b)
-    launch_trsv_fwd_step(s, L, ld, h->Dinv, b, h->nblk, h->w, h->z);
+  order(h, EV_FWD, sp, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
+  // backward substitution alpha = L^-T z on the panel stream: not needed for LML,
+  // overlaps whatever the main stream does next (the triangular inverse)
+  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
+  for (int b = h->nblk - 1; b >= 0; --b)
+    launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, h->nblk, h->w, h->alpha);
+  (void)hipEventRecord(ev(h, EV_ALPHA), sp);
+  h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
   long long info = 0;
   memcpy(&info, h->hscal + 8, sizeof info);
   if (info != 0) {
+    (void)hipStreamSynchronize(sp);
+    h->alpha_pending = false;
     h->notpd = (int64_t)info - 1;
     char buf[160];
     snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)",
@@ -360,17 +433,18 @@ static int factorize(gogp_handle *h) {
   // gp/gp.go:244-253
   h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
   h->factored = true;
+  h->have_alpha = true;
   return GOGP_OK;
 }
 
+// alpha is computed by factorize() on the panel stream; make the main stream
+// wait for it before anything there reads it
 static int ensure_alpha(gogp_handle *h) {
-  if (h->have_alpha) return GOGP_OK;
-  if (!h->factored) return fail(h, GOGP_ESTATE, "no factorisation");
-  hipStream_t s = h->s;
-  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)h->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int b = h->nblk - 1; b >= 0; --b)
-    launch_trsv_bwd_step(s, h->bufL, h->npad, h->Dinv, b, h->nblk, h->w, h->alpha);
-  h->have_alpha = true;
+  if (!h->factored || !h->have_alpha) return fail(h, GOGP_ESTATE, "no factorisation");
+  if (h->alpha_pending) {
+    HIPCHK(h, hipStreamWaitEvent(h->s, ev(h, EV_ALPHA), 0));
+    h->alpha_pending = false;
+  }
   return GOGP_OK;
 }
 
@@ -469,29 +543,41 @@ static int compute_kinv(gogp_handle *h) {
   if (h->have_kinv) return GOGP_OK;
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
+  hipStream_t sp = h->lookahead ? h->sp : h->s;
   if (!h->bufY)
     HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
   double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   launch_set_identity_blocks(s, R, ld, npad);
+  order(h, EV_INIT, s, sp);
   const int npanel = (int)(npad / PANEL);
   for (int m = 0; m < npanel; ++m) {
     const int64_t c0 = (int64_t)m * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
     const double *D0 = h->Dinv + (size_t)(2 * m) * TILE * TILE;
     const double *D1 = D0 + TILE * TILE;
     const int mr = (int)(c2 / TILE);  // block rows 0 .. c2
+    // ---- column panel m of Y (panel stream) -------------------------------------------
     // Y[0:c2, c0:c1] = R[0:c2, c0:c1] * inv(L00)^T
-    launch_dgemm_nt(s, GEMM_RECT, mr, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, Y + c0, ld, pf);
+    launch_dgemm_nt(sp, GEMM_RECT, mr, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, Y + c0, ld, pf);
     // R[0:c1, c1:c2] -= Y[0:c1, c0:c1] * L[c1:c2, c0:c1]^T
-    launch_dgemm_nt(s, GEMM_RECT, mr - 1, 1, TILE, -1.0, Y + c0, ld, L + c1 * ld + c0, ld, 1.0,
+    launch_dgemm_nt(sp, GEMM_RECT, mr - 1, 1, TILE, -1.0, Y + c0, ld, L + c1 * ld + c0, ld, 1.0,
                     R + c1, ld, pf);
     // Y[0:c2, c1:c2] = R[0:c2, c1:c2] * inv(L11)^T
-    launch_dgemm_nt(s, GEMM_RECT, mr, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, Y + c1, ld, pf);
-    // R[0:c2, c2:] -= Y[0:c2, c0:c2] * L[c2:, c0:c2]^T
+    launch_dgemm_nt(sp, GEMM_RECT, mr, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, Y + c1, ld, pf);
+    order(h, EV_BASE + 2 * m, sp, s);
+    // ---- R[0:c2, c2:] -= Y[0:c2, c0:c2] * L[c2:, c0:c2]^T (main stream) ------------------
     const int nt = (int)((npad - c2) / TILE);
-    if (nt > 0)
-      launch_dgemm_nt(s, GEMM_RECT, mr, nt, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
+    if (nt > 0) {
+      const int ntn = nt < 2 ? nt : 2;
+      launch_dgemm_nt(s, GEMM_RECT, mr, ntn, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
                       R + c2, ld, pf);
+      order(h, EV_BASE + 2 * m + 1, s, sp);  // next column panel of R is final
+      if (nt > 2) {
+        const int64_t c3 = c2 + PANEL;
+        launch_dgemm_nt(s, GEMM_RECT, mr, nt - 2, PANEL, -1.0, Y + c0, ld, L + c3 * ld + c0, ld,
+                        1.0, R + c3, ld, pf);
+      }
+    }
   }
   // K^-1 (lower tiles) = Y Y^T, ragged K range; R is dead, write over it
   launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf);
@@ -685,6 +771,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   HIPCHK(h, e);
   h->factored = true;
   h->have_alpha = true;
+  h->alpha_pending = false;
   // LML of the restored state: -n/2 log 2pi - sum log L_ii - 1/2 y^T alpha
   launch_lml_scalars(s, h->bufL, npad, h->alpha, h->dy, h->alpha, n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -723,17 +810,21 @@ extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_
 }
 
 extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) {
-  (void)value;
   if (!h || !name) return GOGP_EARG;
+  if (strcmp(name, "lookahead") == 0) {
+    h->lookahead = value != 0;
+    return GOGP_OK;
+  }
   return fail(h, GOGP_EARG, "unknown option");
 }
 
-extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops) {
+extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                                  double *clock_mhz) {
   if (!tflops || iters <= 0) return GOGP_EARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
-  return mfma_f64_peak(iters, tflops);
+  return mfma_f64_peak(iters, tflops, cyc_per_mfma, clock_mhz);
 }
 
 extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,

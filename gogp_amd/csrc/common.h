@@ -104,6 +104,6 @@ void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n,
                           double *out);
 
-int mfma_f64_peak(int iters, double *tflops);
+int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz);
 
 }  // namespace gogp

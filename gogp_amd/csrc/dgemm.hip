@@ -42,9 +42,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 1);
 }
 
-template <int MODE>
+// BT = workgroup tile (128 or 64).  Always 4 waves in a 2x2 arrangement; each
+// wave owns (BT/2)x(BT/2) outputs = MT x MT MFMA tiles, MT = BT/32.
+template <int MODE, int BT>
 __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double lds[2][2][TILE * GEMM_BK];
+  constexpr int MT = BT / 32;       // MFMA tiles per wave per dimension
+  constexpr int WT = BT / 2;        // rows/cols per wave
+  constexpr int NQ = BT / 32;       // staging loads per thread per operand
+  __shared__ __attribute__((aligned(16))) double lds[2][2][BT * GEMM_BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
@@ -69,21 +74,21 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
   }
-  const int kbeg = (MODE == GEMM_LAUUM) ? ti * TILE : 0;
+  const int kbeg = (MODE == GEMM_LAUUM) ? ti * BT : 0;
   const int nkt = g.nkt - kbeg / GEMM_BK;
 
-  const double *Ag = g.A + (long)ti * TILE * g.lda + kbeg;
-  const double *Bg = g.B + (long)tj * TILE * g.ldb + kbeg;
+  const double *Ag = g.A + (long)ti * BT * g.lda + kbeg;
+  const double *Bg = g.B + (long)tj * BT * g.ldb + kbeg;
 
-  // ---- staging map: thread -> (row, 16-B chunk), 4 rows per operand --------
+  // ---- staging map: thread -> (row, 16-B chunk), NQ rows per operand --------
   const int srow = tid >> 3;  // 0..31, +32*q
   const int schunk = tid & 7;
   const double *Ap = Ag + (long)srow * g.lda + schunk * 2;
   const double *Bp = Bg + (long)srow * g.ldb + schunk * 2;
   const long a_step = 32 * g.lda, b_step = 32 * g.ldb;
-  int soff[4];
+  int soff[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) soff[q] = lds_off(srow + 32 * q, schunk);
+  for (int q = 0; q < NQ; ++q) soff[q] = lds_off(srow + 32 * q, schunk);
 
   // ---- fragment map --------------------------------------------------------
   const int wr = wid >> 1, wc = wid & 1;
@@ -91,28 +96,28 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
   const int fk = lane >> 4;      // k within an MFMA step: 0..3
   const int fchunk = fk >> 1;    // + 2*kk
   const int fhalf = fk & 1;
-  int arow[4], brow[4];
+  int arow[MT], brow[MT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    arow[m] = wr * 64 + m * 16 + frow;
-    brow[m] = wc * 64 + m * 16 + frow;
+  for (int m = 0; m < MT; ++m) {
+    arow[m] = wr * WT + m * 16 + frow;
+    brow[m] = wc * WT + m * 16 + frow;
   }
 
-  f64x4 acc[4][4];
+  f64x4 acc[MT][MT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < MT; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-  f64x2 ra[4], rb[4];
+  f64x2 ra[NQ], rb[NQ];
   // prologue: tile 0
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
     rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     *reinterpret_cast<f64x2 *>(&lds[0][0][soff[q]]) = ra[q];
     *reinterpret_cast<f64x2 *>(&lds[0][1][soff[q]]) = rb[q];
   }
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
       const double *ap = Ap + (long)(kt + 1) * GEMM_BK;
       const double *bp = Bp + (long)(kt + 1) * GEMM_BK;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         ra[q] = *reinterpret_cast<const f64x2 *>(ap + q * a_step);
         rb[q] = *reinterpret_cast<const f64x2 *>(bp + q * b_step);
       }
@@ -134,21 +139,21 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     const double *lb = lds[cur][1];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double a[4], b[4];
+      double a[MT], b[MT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         a[m] = la[lds_off(arow[m], kk * 2 + fchunk) + fhalf];
         b[m] = lb[lds_off(brow[m], kk * 2 + fchunk) + fhalf];
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < MT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
     if (more) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][0][soff[q]]) = ra[q];
         *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][1][soff[q]]) = rb[q];
       }
@@ -159,15 +164,15 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
 
   // ---- epilogue: C/D fragment of v_mfma_f64_16x16x4_f64:
   //      col = lane & 15, row = (lane >> 4) + 4 * reg
-  double *Cg = g.C + (long)(ti * TILE + wr * 64) * g.ldc + tj * TILE + wc * 64;
+  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
   const int ccol = lane & 15;
   const int crow = lane >> 4;
   const double alpha = g.alpha, beta = g.beta;
   if (beta != 0.0) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < MT; ++n)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
@@ -175,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
         }
   } else {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < MT; ++n)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
@@ -230,41 +235,84 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     prof->launches += 1;
     (void)hipEventRecord(e0, s);
   }
-  dim3 grid(ntiles), block(256);
-  switch (mode) {
-    case GEMM_RECT:
-      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_RECT>, grid, block, 0, s, g);
-      break;
-    case GEMM_LOWER:
-      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_LOWER>, grid, block, 0, s, g);
-      break;
-    case GEMM_LAUUM:
-      hipLaunchKernelGGL(dgemm_nt_kernel<GEMM_LAUUM>, grid, block, 0, s, g);
-      break;
+  // Small launches (the skinny GEMMs of the panel chain) use 64x64 tiles: 4x the
+  // workgroups and a quarter of the per-tile latency.  LAUUM keeps 128 (its K
+  // ranges are cut at 128-row granularity).
+  const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
+  dim3 block(256);
+  if (small) {
+    g.mt = mt * 2;
+    g.nt = nt * 2;
+    const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
+    dim3 grid(n64);
+    if (mode == GEMM_RECT)
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64>), grid, block, 0, s, g);
+    else
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64>), grid, block, 0, s, g);
+  } else {
+    dim3 grid(ntiles);
+    switch (mode) {
+      case GEMM_RECT:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128>), grid, block, 0, s, g);
+        break;
+      case GEMM_LOWER:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128>), grid, block, 0, s, g);
+        break;
+      case GEMM_LAUUM:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128>), grid, block, 0, s, g);
+        break;
+    }
   }
   if (e1) (void)hipEventRecord(e1, s);
 }
 
 // ---- fp64 MFMA issue-rate microbenchmark (roofline calibration) -------------
-__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *sink) {
-  f64x4 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+// 8 independent accumulators held in AGPRs by inline asm (the builtin form makes
+// hipcc shuttle loop-carried accumulators between VGPRs and AGPRs every
+// iteration, which under-reads the rate).  Wave 0 of block 0 also reports shader
+// cycles (s_memtime) and wall ticks (s_memrealtime, 100 MHz) around its loop.
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *sink,
+                                                            unsigned long long *clk) {
+  f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
   double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  int cnt = iters;
+  // the whole loop lives in one asm statement so that the accumulators stay in
+  // AGPRs across iterations
+  asm volatile(
+      "1:\n\t"
+      "v_mfma_f64_16x16x4_f64 %0, %9, %10, %0\n\t"
+      "v_mfma_f64_16x16x4_f64 %1, %9, %10, %1\n\t"
+      "v_mfma_f64_16x16x4_f64 %2, %9, %10, %2\n\t"
+      "v_mfma_f64_16x16x4_f64 %3, %9, %10, %3\n\t"
+      "v_mfma_f64_16x16x4_f64 %4, %9, %10, %4\n\t"
+      "v_mfma_f64_16x16x4_f64 %5, %9, %10, %5\n\t"
+      "v_mfma_f64_16x16x4_f64 %6, %9, %10, %6\n\t"
+      "v_mfma_f64_16x16x4_f64 %7, %9, %10, %7\n\t"
+      "s_sub_u32 %8, %8, 1\n\t"
+      "s_cmp_lg_u32 %8, 0\n\t"
+      "s_cbranch_scc1 1b"
+      : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7),
+        "+s"(cnt)
+      : "v"(a), "v"(b)
+      : "scc");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  double s = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+  if (s == 12345.678) sink[0] = s;  // keep the chains live
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
   }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  if (s == 12345.678) sink[0] = s;  // keep the chain live
 }
 
-int mfma_f64_peak(int iters, double *tflops) {
+// tflops: achieved rate with every SIMD issuing; cyc_per_mfma / clock_mhz from wave 0.
+int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz) {
   double *sink = nullptr;
+  unsigned long long *clk = nullptr;
   if (hipMalloc(&sink, 8) != hipSuccess) return GOGP_EHIP;
+  if (hipMalloc(&clk, 16) != hipSuccess) return GOGP_EHIP;
   hipDeviceProp_t prop;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -273,19 +321,25 @@ int mfma_f64_peak(int iters, double *tflops) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, 64, sink);
-  (void)hipDeviceSynchronize();
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters / 4 + 1, sink,
+                     (unsigned long long *)nullptr);  // warm-up (clock ramp)
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink, clk);
   (void)hipEventRecord(e1, 0);
   if (hipEventSynchronize(e1) != hipSuccess) return GOGP_EHIP;
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
   const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
   *tflops = flops / (ms * 1e-3) / 1e12;
+  unsigned long long h[2] = {0, 0};
+  (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  // two waves share a SIMD: cycles per MFMA issued on that SIMD
+  if (cyc_per_mfma) *cyc_per_mfma = (double)h[0] / ((double)iters * 8.0 * 2.0);
+  if (clock_mhz) *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(sink);
+  (void)hipFree(clk);
   return GOGP_OK;
 }
 

@@ -100,14 +100,19 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
   }
 }
 
-// out[q] = sum over blocks of partials[b][q], fixed order
-__global__ __launch_bounds__(128) void grad_final_kernel(const double *__restrict__ partials,
+// out[q] = sum over blocks of partials[b][q]; one workgroup per slot q, fixed
+// summation tree (bitwise reproducible)
+__global__ __launch_bounds__(256) void grad_final_kernel(const double *__restrict__ partials,
                                                          int nblocks, double *__restrict__ out) {
-  const int q = threadIdx.x;
-  if (q >= NACC) return;
+  __shared__ double red[4];
+  const int q = blockIdx.x;
   double v = 0.0;
-  for (int b = 0; b < nblocks; ++b) v += partials[(long)b * NACC + q];
-  out[q] = v;
+  for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(long)b * NACC + q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[q] = red[0] + red[1] + red[2] + red[3];
 }
 
 int grad_reduce_blocks(int64_t npad) {
@@ -132,7 +137,7 @@ void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dim
   else if (ard_dims <= 32) GOGP_LAUNCH_GR(32);
   else GOGP_LAUNCH_GR(64);
 #undef GOGP_LAUNCH_GR
-  hipLaunchKernelGGL(grad_final_kernel, dim3(1), dim3(128), 0, s, partials, blocks, out);
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
 }
 
 }  // namespace gogp

@@ -17,16 +17,32 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // out[r] = sum_c M[r][c] * v[c]   (M 128x128 row-major with leading dim ldm),
 // computed by a 256-thread workgroup; v in LDS; result to LDS res[128].
+// 16 lanes share a row (8 consecutive columns each, 1 KB contiguous per row),
+// 4 rows per wave-iteration, 4 xor-shuffles per 4 rows.
 __device__ __forceinline__ void block_matvec(const double *__restrict__ M, long ldm,
                                              const double *v, double *res) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  // wave w handles rows w*32 .. w*32+31; 64 lanes cover the 128 columns
-  const double v0 = v[2 * lane], v1 = v[2 * lane + 1];
-  for (int r = wid * 32; r < wid * 32 + 32; ++r) {
-    const double2 m = *reinterpret_cast<const double2 *>(M + (long)r * ldm + 2 * lane);
-    double p = m.x * v0 + m.y * v1;
-    p = wave_sum(p);
-    if (lane == 0) res[r] = p;
+  const int rsub = lane >> 4, cg = lane & 15;
+  double vv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vv[k] = v[cg * 8 + k];
+  double p[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = wid * 32 + it * 4 + rsub;
+    const double2 *mp = reinterpret_cast<const double2 *>(M + (long)r * ldm + cg * 8);
+    const double2 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+    p[it] = m0.x * vv[0] + m0.y * vv[1] + m1.x * vv[2] + m1.y * vv[3] + m2.x * vv[4] +
+            m2.y * vv[5] + m3.x * vv[6] + m3.y * vv[7];
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    double q = p[it];
+    q += __shfl_xor(q, 8);
+    q += __shfl_xor(q, 4);
+    q += __shfl_xor(q, 2);
+    q += __shfl_xor(q, 1);
+    if (cg == 0) res[wid * 32 + it * 4 + rsub] = q;
   }
 }
 

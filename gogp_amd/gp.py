@@ -235,6 +235,9 @@ class GP:
         self._check(_lib.lib().gogp_set_factor(self._h, _dp(ts), _dp(tn), _dp(Lm), _dp(al)))
 
     # ---- measurement hooks ----------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        self._check(_lib.lib().gogp_set_option(self._h, name.encode(), int(value)))
+
     def profile_enable(self, on: bool = True):
         self._check(_lib.lib().gogp_profile_enable(self._h, 1 if on else 0))
 
@@ -268,13 +271,15 @@ class Model:
         return g
 
 
-def mfma_f64_peak(iters: int = 20000, device: int = -1) -> float:
-    """fp64 MFMA issue-rate microbenchmark (TFLOP/s) used to calibrate the roofline."""
-    v = ctypes.c_double(0.0)
-    rc = _lib.lib().gogp_mfma_f64_peak(device, iters, ctypes.byref(v))
+def mfma_f64_peak(iters: int = 20000, device: int = -1, details: bool = False):
+    """fp64 MFMA issue-rate microbenchmark used to calibrate the roofline:
+    TFLOP/s, or (TFLOP/s, cycles per MFMA on one SIMD, shader clock MHz)."""
+    v, c, m = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = _lib.lib().gogp_mfma_f64_peak(device, iters, ctypes.byref(v), ctypes.byref(c),
+                                       ctypes.byref(m))
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "mfma_f64_peak")
-    return v.value
+    return (v.value, c.value, m.value) if details else v.value
 
 
 def dgemm_nt_check(A: np.ndarray, B: np.ndarray, C: np.ndarray, alpha=1.0, beta=0.0,

@@ -199,10 +199,12 @@ int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 /* Library build info: "gogp_hip <version> gfx950 ..." */
 const char *gogp_version(void);
 
-/* Micro-benchmark used to calibrate the fp64 MFMA roofline: issues `iters`
- * back-to-back v_mfma_f64_16x16x4_f64 per wave on every SIMD and returns the
- * achieved TFLOP/s. */
-int gogp_mfma_f64_peak(int device, int iters, double *tflops);
+/* Micro-benchmark used to calibrate the fp64 MFMA roofline: every SIMD issues
+ * `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64 from two waves; returns the
+ * achieved TFLOP/s and (optionally) the shader cycles per MFMA on one SIMD and
+ * the shader clock in MHz observed by one wave during the run. */
+int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                       double *clock_mhz);
 
 /* Stand-alone fp64 GEMM test hook: C(MxN,row-major) = beta*C + alpha*A(MxK)*B(NxK)^T
  * on host buffers (copied to the device and back); M,N multiples of 128,

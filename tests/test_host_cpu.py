@@ -98,7 +98,7 @@ def test_no_gpu_fails_loudly(lib):
         gp.GP(1, kernel.Normal)
     assert ei.value.code == _lib.GOGP_EHIP
     v = ctypes.c_double()
-    assert lib.gogp_mfma_f64_peak(0, 10, ctypes.byref(v)) == _lib.GOGP_EHIP
+    assert lib.gogp_mfma_f64_peak(0, 10, ctypes.byref(v), None, None) == _lib.GOGP_EHIP
 
 
 def test_product_does_not_import_oracle():

@@ -5,15 +5,18 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from gogp_amd import kernel  # noqa: E402
 from gogp_amd import gp as G  # noqa: E402
 
 print("version:", G._lib.lib().gogp_version().decode(), flush=True)
-for it in (2000, 20000):
-    print("mfma f64 peak iters=%d: %.2f TFLOP/s" % (it, G.mfma_f64_peak(it)), flush=True)
+for it in (2000, 20000, 100000):
+    print("mfma f64 peak iters=%d: %.2f TFLOP/s, %.1f cycles/MFMA/SIMD, clock %.0f MHz"
+          % ((it,) + G.mfma_f64_peak(it, details=True)), flush=True)
 
+import os
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096]
+opts = [kv.split("=") for kv in os.environ.get("GOGP_OPTS", "").split(",") if kv]
 for n in sizes:
     D = 8
     rng = np.random.default_rng(n)
@@ -22,6 +25,8 @@ for n in sizes:
     y = (y - y.mean()) / y.std()
     g = G.GP(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=X, Y=y)
     x0 = np.log([1.0, math.sqrt(D / 6.0), 0.1])
+    for k_, v_ in opts:
+        g.set_option(k_, int(v_))
     t = time.time(); lml = g.Observe(x0); t_first = time.time() - t
     t = time.time(); gr = g.Gradient(); t_gfirst = time.time() - t
     g.profile_enable(True)
