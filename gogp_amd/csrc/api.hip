@@ -9,14 +9,15 @@
 //          finally holds K^-1 (lower triangle).
 //   bufL : the lower Cholesky factor L (gp.GP.L, gp/gp.go:35).
 //   bufY : Y = L^-T (upper triangular), allocated on the first Gradient.
-//   Dinv : inverse of every 128x128 diagonal block of L (npad/128 blocks).
+//   Dinv : dense inverse of every 256x256 diagonal block of L (npad/256 blocks).
 //   X (npad x D), y, z = L^-1 y, alpha = K^-1 y (gp.GP.Alpha, gp/gp.go:36).
 //
 // Step list of one Observe + Gradient (reference call stack: SURVEY.md 3.1):
-//   gram_lower -> per 256-panel { diag128, TRSM-as-GEMM, half-panel update,
-//   diag128, TRSM-as-GEMM, SYRK K=256 } -> forward solve -> LML scalars
-//   -> [Gradient] identity fill, per panel { Y=R*Dinv^T x2, updates } ->
-//   LAUUM (K^-1 = Y Y^T) -> backward solve (alpha) -> fused gradient reduce.
+//   gram_lower -> per 256-panel { diag256 (factor + inverse of the diagonal block),
+//   panel solve as ONE GEMM with the inverse, forward-substitution step | next
+//   block column update, SYRK K=256 of the rest } -> LML scalars
+//   -> [Gradient] identity fill, per panel { Y = R*Dinv^T | R updates } ->
+//   LAUUM (K^-1 = Y Y^T) -> fused gradient reduce.   ("|" = two streams)
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -258,7 +259,7 @@ static int ensure_n(gogp_handle *h, int64_t n) {
     HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->bufA, nn));
     HIPCHK(h, hipMalloc(&h->bufL, nn));
-    HIPCHK(h, hipMalloc(&h->Dinv, (size_t)(npad / TILE) * TILE * TILE * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->Dinv, (size_t)(npad / PANEL) * PANEL * PANEL * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->w, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
@@ -368,27 +369,20 @@ static int factorize(gogp_handle *h) {
   HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
   for (int p = 0; p < npanel; ++p) {
     const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    double *D0 = h->Dinv + (size_t)(2 * p) * TILE * TILE;
-    double *D1 = D0 + TILE * TILE;
+    double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+    (void)c1;
     // ---- panel factorisation (panel stream) ---------------------------------------
-    launch_diag128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, D0, c0, h->n, h->info);
-    const int mt1 = (int)((npad - c1) / TILE);
-    // L[c1:, c0:c1] = A[c1:, c0:c1] * inv(L00)^T
-    launch_dgemm_nt(sp, GEMM_RECT, mt1, 1, TILE, 1.0, A + c1 * ld + c0, ld, D0, TILE, 0.0,
-                    L + c1 * ld + c0, ld, pf);
-    // A[c1:, c1:c2] -= L[c1:, c0:c1] * L[c1:c2, c0:c1]^T
-    launch_dgemm_nt(sp, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0,
-                    ld, 1.0, A + c1 * ld + c1, ld, pf);
-    launch_diag128(sp, A + c1 * ld + c1, ld, L + c1 * ld + c1, ld, D1, c1, h->n, h->info);
+    // 256x256 diagonal block: factor + dense inverse, one workgroup
+    launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
     const int mt2 = (int)((npad - c2) / TILE);
+    // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
     if (mt2 > 0)
-      launch_dgemm_nt(sp, GEMM_RECT, mt2, 1, TILE, 1.0, A + c2 * ld + c1, ld, D1, TILE, 0.0,
-                      L + c2 * ld + c1, ld, pf);
+      launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
+                      L + c2 * ld + c0, ld, pf);
     order(h, EV_BASE + 2 * p, sp, s);  // panel p of L is final
-    // forward substitution steps of this panel fill the panel stream's wait for
-    // the next block column
-    launch_trsv_fwd_step(sp, L, ld, h->Dinv, 2 * p, h->nblk, h->w, h->z);
-    launch_trsv_fwd_step(sp, L, ld, h->Dinv, 2 * p + 1, h->nblk, h->w, h->z);
+    // the forward substitution step of this panel fills the panel stream's wait
+    // for the next block column
+    launch_trsv_fwd_step(sp, L, ld, h->Dinv, p, npanel, h->w, h->z);
     // ---- trailing update, rank 256 (main stream) ------------------------------------
     if (mt2 > 0) {
       const int ntn = mt2 < 2 ? mt2 : 2;
@@ -411,8 +405,8 @@ static int factorize(gogp_handle *h) {
   // backward substitution alpha = L^-T z on the panel stream: not needed for LML,
   // overlaps whatever the main stream does next (the triangular inverse)
   HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
-  for (int b = h->nblk - 1; b >= 0; --b)
-    launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, h->nblk, h->w, h->alpha);
+  for (int b = npanel - 1; b >= 0; --b)
+    launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
   (void)hipEventRecord(ev(h, EV_ALPHA), sp);
   h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
@@ -553,17 +547,11 @@ static int compute_kinv(gogp_handle *h) {
   const int npanel = (int)(npad / PANEL);
   for (int m = 0; m < npanel; ++m) {
     const int64_t c0 = (int64_t)m * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    const double *D0 = h->Dinv + (size_t)(2 * m) * TILE * TILE;
-    const double *D1 = D0 + TILE * TILE;
+    const double *Dm = h->Dinv + (size_t)m * PANEL * PANEL;
     const int mr = (int)(c2 / TILE);  // block rows 0 .. c2
-    // ---- column panel m of Y (panel stream) -------------------------------------------
-    // Y[0:c2, c0:c1] = R[0:c2, c0:c1] * inv(L00)^T
-    launch_dgemm_nt(sp, GEMM_RECT, mr, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, Y + c0, ld, pf);
-    // R[0:c1, c1:c2] -= Y[0:c1, c0:c1] * L[c1:c2, c0:c1]^T
-    launch_dgemm_nt(sp, GEMM_RECT, mr - 1, 1, TILE, -1.0, Y + c0, ld, L + c1 * ld + c0, ld, 1.0,
-                    R + c1, ld, pf);
-    // Y[0:c2, c1:c2] = R[0:c2, c1:c2] * inv(L11)^T
-    launch_dgemm_nt(sp, GEMM_RECT, mr, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, Y + c1, ld, pf);
+    (void)c1;
+    // ---- column panel m of Y (panel stream): Y[0:c2, c0:c2] = R[0:c2, c0:c2] inv(L_mm)^T
+    launch_dgemm_nt(sp, GEMM_RECT, mr, 2, PANEL, 1.0, R + c0, ld, Dm, PANEL, 0.0, Y + c0, ld, pf);
     order(h, EV_BASE + 2 * m, sp, s);
     // ---- R[0:c2, c2:] -= Y[0:c2, c0:c2] * L[c2:, c0:c2]^T (main stream) ------------------
     const int nt = (int)((npad - c2) / TILE);
@@ -686,12 +674,9 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   const int npanel = (int)(npad / PANEL);
   for (int p = 0; p < npanel; ++p) {
     const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    const double *D0 = h->Dinv + (size_t)(2 * p) * TILE * TILE;
-    const double *D1 = D0 + TILE * TILE;
-    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, 1.0, R + c0, ld, D0, TILE, 0.0, V + c0, ld, pf);
-    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, -1.0, V + c0, ld, L + c1 * ld + c0, ld, 1.0,
-                    R + c1, ld, pf);
-    launch_dgemm_nt(s, GEMM_RECT, mt, 1, TILE, 1.0, R + c1, ld, D1, TILE, 0.0, V + c1, ld, pf);
+    const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+    (void)c1;
+    launch_dgemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf);
     const int nt = (int)((npad - c2) / TILE);
     if (nt > 0)
       launch_dgemm_nt(s, GEMM_RECT, mt, nt, PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld, 1.0,
@@ -758,9 +743,9 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   hipError_t e = hipMemcpyAsync(tmp, Lin, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     launch_pack_lower(s, tmp, n, npad, h->bufL, npad);
-    for (int b = 0; b < h->nblk; ++b)
-      launch_diag128_inv_only(s, h->bufL + (size_t)b * TILE * npad + (size_t)b * TILE, npad,
-                              h->Dinv + (size_t)b * TILE * TILE);
+    for (int b = 0; b < (int)(npad / PANEL); ++b)
+      launch_diag256_inv_only(s, h->bufL + (size_t)b * PANEL * npad + (size_t)b * PANEL, npad,
+                              h->Dinv + (size_t)b * PANEL * PANEL);
     e = hipMemsetAsync(h->alpha, 0, (size_t)npad * sizeof(double), s);
   }
   if (e == hipSuccess)
@@ -850,5 +835,53 @@ extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, d
   (void)hipFree(dA);
   (void)hipFree(dB);
   (void)hipFree(dC);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
+// Diagnostic: factor+invert one 256x256 SPD block (host buffers) with the stamped
+// build of the diagonal kernel; returns the factor, the inverse and 24 s_memtime stamps.
+namespace gogp {
+void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
+                            long long *info, unsigned long long *stamps);
+}
+extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
+                                 unsigned long long *stamps, double *elapsed_us) {
+  if (!A || !Lout || !Dinv || !stamps) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
+  long long *dinfo = nullptr;
+  unsigned long long *dst = nullptr;
+  const size_t nb = 256 * 256 * sizeof(double);
+  hipError_t e = hipMalloc(&dA, nb);
+  if (e == hipSuccess) e = hipMalloc(&dL, nb);
+  if (e == hipSuccess) e = hipMalloc(&dD, nb);
+  if (e == hipSuccess) e = hipMalloc(&dinfo, 8);
+  if (e == hipSuccess) e = hipMalloc(&dst, 32 * 8);
+  if (e == hipSuccess) e = hipMemcpy(dA, A, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dinfo, 0, 8);
+  if (e == hipSuccess) e = hipMemset(dst, 0, 32 * 8);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);  // warm-up
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    launch_diag256(0, dA, 256, dL, 256, dD, 0, 256, dinfo);  // product build, timed
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(Lout, dL, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(Dinv, dD, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(stamps, dst, 32 * 8, hipMemcpyDeviceToHost);
+  if (elapsed_us) *elapsed_us = ms * 1e3;
+  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dinfo); (void)hipFree(dst);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
 }

@@ -73,7 +73,8 @@ void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout,
                     int64_t ldl, double *Dinv, int64_t row0, int64_t nvalid,
                     long long *info);
 
-// forward / backward substitution steps with the stored block inverses
+// forward / backward substitution steps with the stored 256x256 block inverses
+// (b, nb count 256-blocks)
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nblk, double *y, double *z);
 void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
@@ -84,6 +85,11 @@ void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const doub
 void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars);
 void launch_diag128_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
+// potrf + dense inverse of one 256x256 diagonal block (diag256.hip); Dinv has
+// leading dimension 256.
+void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                    double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld);
 void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,

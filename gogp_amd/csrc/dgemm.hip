@@ -103,18 +103,36 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     brow[m] = wc * WT + m * 16 + frow;
   }
 
-  f64x4 acc[MT][MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < MT; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // C fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
+  const int ccol = lane & 15;
+  const int crow = lane >> 4;
+  const double alpha = g.alpha, beta = g.beta;
 
   f64x2 ra[NQ], rb[NQ];
-  // prologue: tile 0
+  // prologue loads of k-tile 0 go out first, the C tile right behind them: the
+  // accumulators start at (beta/alpha) C, so the epilogue is stores only and the
+  // C read latency overlaps the operand pipeline fill
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
     rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
+  }
+  f64x4 acc[MT][MT];
+  if (beta != 0.0) {
+    const double sc = beta / alpha;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < MT; ++n)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          acc[m][n][v] = sc * Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol];
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < MT; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -162,33 +180,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     cur ^= 1;
   }
 
-  // ---- epilogue: C/D fragment of v_mfma_f64_16x16x4_f64:
-  //      col = lane & 15, row = (lane >> 4) + 4 * reg
-  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
-  const int ccol = lane & 15;
-  const int crow = lane >> 4;
-  const double alpha = g.alpha, beta = g.beta;
-  if (beta != 0.0) {
+  // ---- epilogue: stores only
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < MT; ++n)
+    for (int n = 0; n < MT; ++n)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
-          *p = alpha * acc[m][n][v] + beta * (*p);
-        }
-  } else {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < MT; ++n)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          double *p = Cg + (long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol;
-          *p = alpha * acc[m][n][v];
-        }
-  }
+      for (int v = 0; v < 4; ++v)
+        Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol] = alpha * acc[m][n][v];
 }
 
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,

@@ -15,102 +15,113 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// out[r] = sum_c M[r][c] * v[c]   (M 128x128 row-major with leading dim ldm),
-// computed by a 256-thread workgroup; v in LDS; result to LDS res[128].
-// 16 lanes share a row (8 consecutive columns each, 1 KB contiguous per row),
-// 4 rows per wave-iteration, 4 xor-shuffles per 4 rows.
-__device__ __forceinline__ void block_matvec(const double *__restrict__ M, long ldm,
-                                             const double *v, double *res) {
+// res[r] = sum_c M[r][c] * v[c] for 128 rows x 256 columns (M row-major, ldm),
+// 256-thread workgroup, v[256] and res[128] in LDS.  32 lanes share a row
+// (8 consecutive columns each: 2 KB contiguous per row), 2 rows per
+// wave-iteration, 5 xor-shuffles per pair of rows.
+__device__ __forceinline__ void matvec_128x256(const double *__restrict__ M, long ldm,
+                                               const double *v, double *res) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int rsub = lane >> 4, cg = lane & 15;
+  const int rsub = lane >> 5, cg = lane & 31;
   double vv[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) vv[k] = v[cg * 8 + k];
-  double p[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = wid * 32 + it * 4 + rsub;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = wid * 32 + it * 2 + rsub;
     const double2 *mp = reinterpret_cast<const double2 *>(M + (long)r * ldm + cg * 8);
     const double2 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
-    p[it] = m0.x * vv[0] + m0.y * vv[1] + m1.x * vv[2] + m1.y * vv[3] + m2.x * vv[4] +
-            m2.y * vv[5] + m3.x * vv[6] + m3.y * vv[7];
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    double q = p[it];
+    double q = m0.x * vv[0] + m0.y * vv[1] + m1.x * vv[2] + m1.y * vv[3] + m2.x * vv[4] +
+               m2.y * vv[5] + m3.x * vv[6] + m3.y * vv[7];
+    q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 8);
     q += __shfl_xor(q, 4);
     q += __shfl_xor(q, 2);
     q += __shfl_xor(q, 1);
-    if (cg == 0) res[wid * 32 + it * 4 + rsub] = q;
+    if (cg == 0) res[r] = q;
   }
 }
 
-// out[c] = sum_r M[r][c] * v[r]  (transposed product), 256 threads
-__device__ __forceinline__ void block_matvec_t(const double *__restrict__ M, long ldm,
-                                               const double *v, double *res, double *scratch) {
+// res[c] = sum_r M[r][c] * v[r] for 256 rows x 128 columns, 256 threads
+__device__ __forceinline__ void matvec_t_256x128(const double *__restrict__ M, long ldm,
+                                                 const double *v, double *res, double *scratch) {
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-  double p = 0.0;
-  for (int r = half * 64; r < half * 64 + 64; ++r) p += M[(long)r * ldm + c] * v[r];
+  double p0 = 0.0, p1 = 0.0;
+  for (int r = half * 128; r < half * 128 + 128; r += 2) {
+    p0 += M[(long)r * ldm + c] * v[r];
+    p1 += M[(long)(r + 1) * ldm + c] * v[r + 1];
+  }
+  const double p = p0 + p1;
   if (half == 1) scratch[c] = p;
   __syncthreads();
   if (half == 0) res[c] = p + scratch[c];
+  __syncthreads();
 }
 
-// Forward step b: z_b = Dinv_b * w_b ; w_i -= L[i,b] z_b  (i > b).
-// grid = nblk - b workgroups; workgroup g handles block row i = b + g.
+// Forward step b (256-blocks): z_b = Dinv_b w_b ; w_i -= L[i,b] z_b  (i > b).
+// Workgroup g handles 128 rows: g = 0,1 the halves of z_b, g >= 2 rows
+// (b+1)*256 + (g-2)*128 ...  Every workgroup recomputes z_b (Dinv_b is L2-resident).
 __global__ __launch_bounds__(256) void trsv_fwd_kernel(const double *__restrict__ L, long ld,
                                                        const double *__restrict__ Dinv, int b,
                                                        double *__restrict__ w,
                                                        double *__restrict__ z) {
-  __shared__ double vb[128], zb[128], upd[128];
+  __shared__ double vb[256], zb[256], upd[128];
   const int tid = threadIdx.x;
-  const int i = b + blockIdx.x;
-  if (tid < 128) vb[tid] = w[(long)b * 128 + tid];
+  const int g = blockIdx.x;
+  vb[tid] = w[(long)b * 256 + tid];
   __syncthreads();
-  block_matvec(Dinv + (long)b * 128 * 128, 128, vb, zb);
-  __syncthreads();
-  if (i == b) {
-    if (tid < 128) z[(long)b * 128 + tid] = zb[tid];
+  const double *Db = Dinv + (long)b * 256 * 256;
+  if (g < 2) {
+    matvec_128x256(Db + (long)g * 128 * 256, 256, vb, zb);
+    __syncthreads();
+    if (tid < 128) z[(long)b * 256 + g * 128 + tid] = zb[tid];
     return;
   }
-  block_matvec(L + (long)i * 128 * ld + (long)b * 128, ld, zb, upd);
+  matvec_128x256(Db, 256, vb, zb);
+  matvec_128x256(Db + 128 * 256, 256, vb, zb + 128);
   __syncthreads();
-  if (tid < 128) w[(long)i * 128 + tid] -= upd[tid];
+  const long r0 = (long)(b + 1) * 256 + (long)(g - 2) * 128;
+  matvec_128x256(L + r0 * ld + (long)b * 256, ld, zb, upd);
+  __syncthreads();
+  if (tid < 128) w[r0 + tid] -= upd[tid];
 }
 
-// Backward step b: alpha_b = Dinv_b^T * w_b ; w_i -= L[b,i]^T alpha_b  (i < b).
-// grid = b + 1 workgroups; workgroup g handles block column i = g.
+// Backward step b: alpha_b = Dinv_b^T w_b ; w_i -= L[b,i]^T alpha_b  (i < b).
+// Workgroup g handles 128 columns: g = 0,1 the halves of alpha_b, g >= 2
+// columns (g-2)*128 ... of the block row b of L.
 __global__ __launch_bounds__(256) void trsv_bwd_kernel(const double *__restrict__ L, long ld,
                                                        const double *__restrict__ Dinv, int b,
                                                        double *__restrict__ w,
                                                        double *__restrict__ alpha) {
-  __shared__ double vb[128], ab[128], upd[128], scratch[128];
+  __shared__ double vb[256], ab[256], upd[128], scratch[128];
   const int tid = threadIdx.x;
-  const int i = blockIdx.x;
-  if (tid < 128) vb[tid] = w[(long)b * 128 + tid];
+  const int g = blockIdx.x;
+  vb[tid] = w[(long)b * 256 + tid];
   __syncthreads();
-  block_matvec_t(Dinv + (long)b * 128 * 128, 128, vb, ab, scratch);
-  __syncthreads();
-  if (i == b) {
-    if (tid < 128) alpha[(long)b * 128 + tid] = ab[tid];
+  const double *Db = Dinv + (long)b * 256 * 256;
+  if (g < 2) {
+    matvec_t_256x128(Db + g * 128, 256, vb, ab, scratch);
+    if (tid < 128) alpha[(long)b * 256 + g * 128 + tid] = ab[tid];
     return;
   }
-  block_matvec_t(L + (long)b * 128 * ld + (long)i * 128, ld, ab, upd, scratch);
-  __syncthreads();
-  if (tid < 128) w[(long)i * 128 + tid] -= upd[tid];
+  matvec_t_256x128(Db, 256, vb, ab, scratch);
+  matvec_t_256x128(Db + 128, 256, vb, ab + 128, scratch);
+  const long c0 = (long)(g - 2) * 128;
+  matvec_t_256x128(L + (long)b * 256 * ld + c0, ld, ab, upd, scratch);
+  if (tid < 128) w[c0 + tid] -= upd[tid];
 }
 
+// nb = number of 256-blocks
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
-                          int b, int nblk, double *w, double *z) {
-  hipLaunchKernelGGL(trsv_fwd_kernel, dim3(nblk - b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
-                     z);
+                          int b, int nb, double *w, double *z) {
+  hipLaunchKernelGGL(trsv_fwd_kernel, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
+                     Dinv, b, w, z);
 }
 
 void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
-                          int b, int nblk, double *w, double *alpha) {
-  (void)nblk;
-  hipLaunchKernelGGL(trsv_bwd_kernel, dim3(b + 1), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+                          int b, int nb, double *w, double *alpha) {
+  (void)nb;
+  hipLaunchKernelGGL(trsv_bwd_kernel, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
                      alpha);
 }
 

@@ -293,3 +293,17 @@ def dgemm_nt_check(A: np.ndarray, B: np.ndarray, C: np.ndarray, alpha=1.0, beta=
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "test_dgemm_nt")
     return out
+
+
+def diag256_check(A: np.ndarray, device: int = -1):
+    """Factor + invert one 256x256 SPD block on the diagonal-block kernel (test /
+    diagnostic hook): returns (L, Linv, stamps[24], elapsed_us)."""
+    A = _arr(A)
+    assert A.shape == (256, 256)
+    L, X = np.zeros((256, 256)), np.zeros((256, 256))
+    st = (ctypes.c_uint64 * 32)()
+    us = ctypes.c_double(0.0)
+    rc = _lib.lib().gogp_test_diag256(device, _dp(A), _dp(L), _dp(X), st, ctypes.byref(us))
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "test_diag256")
+    return L, X, np.array(list(st), dtype=np.uint64), us.value

@@ -213,6 +213,13 @@ int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mf
 int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
                        const double *A, const double *B, double beta, double *C);
 
+/* Diagnostic hook for the diagonal-block kernel: factor + invert one 256x256 SPD
+ * block given on the host (row-major, lower triangle used); returns the factor,
+ * its dense inverse, 24 in-kernel s_memtime stamps of a diagnostic build and the
+ * HIP-event time (us) of the product build. */
+int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
+                      unsigned long long *stamps, double *elapsed_us);
+
 #ifdef __cplusplus
 }
 #endif
