@@ -57,8 +57,14 @@ struct gogp_handle {
   hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
   hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
                              // skinny updates, substitution steps -- overlaps the big updates
+  hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
+  hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
+  int eager = 1;               // Observe also runs the triangular inverse (gradient
+                               // preparation), interleaved with the Cholesky sweep
+  bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
+  bool trtri_pending = false;  // ... and still running on st/s2 (wait for EV_TRTRI)
   bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
   // state
   std::vector<double> theta_s, theta_n;
@@ -170,8 +176,10 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  if (h->sp) (void)hipStreamSynchronize(h->sp);
-  if (h->sp) (void)hipStreamDestroy(h->sp);
+  for (hipStream_t q : {h->sp, h->s2, h->st}) {
+    if (q) (void)hipStreamSynchronize(q);
+    if (q) (void)hipStreamDestroy(q);
+  }
   if (h->s) (void)hipStreamDestroy(h->s);
   delete h;
 }
@@ -228,6 +236,8 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking);
   }
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
@@ -252,6 +262,7 @@ static int ensure_n(gogp_handle *h, int64_t n) {
   h->npad = npad;
   h->nblk = (int)(npad / TILE);
   h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
+  h->trtri_done = false;
   if (npad > h->cap_npad) {
     free_n_buffers(h);
     const size_t nn = (size_t)npad * (size_t)npad * sizeof(double);
@@ -276,6 +287,10 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   if (!h) return GOGP_EARG;
   if (n < 0 || (n > 0 && (!X || !y))) return fail(h, GOGP_EARG, "set_data: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
+  // nothing of a previous evaluation may still be running when buffers are
+  // replaced or re-filled
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_pending = h->alpha_pending = false;
   int rc = ensure_n(h, n);
   if (rc != GOGP_OK) return rc;
   h->have_data = true;
@@ -331,7 +346,9 @@ static int upload_params(gogp_handle *h) {
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_BASE = 4 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_BASE = 8 };
+// per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
+//                              2: column panel p of Y final, 3: next column panel of R final}
 static hipEvent_t ev(gogp_handle *h, size_t i) {
   while (h->evs.size() <= i) {
     hipEvent_t e = nullptr;
@@ -349,19 +366,70 @@ static void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
 }
 
 // ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
-static int factorize(gogp_handle *h) {
+// One step of the triangular inverse Y = L^-T (upper), column panel m:
+//   Y[c0:c2, c0:c2] = inv(L_mm)^T ;  Y[0:c0, c0:c2] = R[0:c0, c0:c2] inv(L_mm)^T      (chain, st)
+//   R[0:c2, c2:]   -= Y[0:c2, c0:c2] L[c2:, c0:c2]^T                                  (updates, s2)
+// R occupies the strictly upper 256-block triangle of bufA (zero-initialised),
+// which the Cholesky sweep never touches: step m only needs panel m of L and its
+// diagonal inverse, so it can run right behind the factorisation of panel m.
+static void trtri_step(gogp_handle *h, int m, hipStream_t st, hipStream_t s2) {
+  const int64_t npad = h->npad, ld = npad;
+  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
+  GemmProfile *pf = &h->prof;
+  const int64_t c0 = (int64_t)m * PANEL, c2 = c0 + PANEL;
+  const double *Dm = h->Dinv + (size_t)m * PANEL * PANEL;
+  const int mr = (int)(c2 / TILE);
+  if (m > 0 && st != s2) (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (m - 1) + 3), 0);
+  launch_ydiag(st, Dm, Y + c0 * ld + c0, ld);
+  if (m > 0)
+    launch_dgemm_nt(st, GEMM_RECT, mr - 2, 2, PANEL, 1.0, R + c0, ld, Dm, PANEL, 0.0, Y + c0, ld,
+                    pf);
+  order(h, EV_BASE + 4 * m + 2, st, s2);
+  const int nt = (int)((npad - c2) / TILE);
+  if (nt > 0) {
+    const int ntn = nt < 2 ? nt : 2;
+    launch_dgemm_nt(s2, GEMM_RECT, mr, ntn, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
+                    R + c2, ld, pf);
+    (void)hipEventRecord(ev(h, EV_BASE + 4 * m + 3), s2);
+    if (nt > 2) {
+      const int64_t c3 = c2 + PANEL;
+      launch_dgemm_nt(s2, GEMM_RECT, mr, nt - 2, PANEL, -1.0, Y + c0, ld, L + c3 * ld + c0, ld,
+                      1.0, R + c3, ld, pf);
+    }
+  }
+}
+
+static int factorize(gogp_handle *h, bool eager) {
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
   // without lookahead everything runs in order on the main stream
   hipStream_t sp = h->lookahead ? h->sp : h->s;
+  // streams of the fused triangular-inverse sweep (only with lookahead + eager)
+  eager = eager && h->lookahead;
+  hipStream_t st = h->st, s2 = h->s2;
+  if (h->trtri_pending) {
+    // a previous Observe left its triangular inverse running: it reads L / Dinv
+    (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+    (void)hipStreamWaitEvent(sp, ev(h, EV_TRTRI), 0);
+    h->trtri_pending = false;
+  }
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
+  h->trtri_done = false;
   h->notpd = -1;
   int rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
+  if (eager && !h->bufY)
+    HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
   launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
   order(h, EV_GRAM, s, sp);
+  if (eager) {
+    // R := 0 on the strictly upper block triangle (after whatever used bufA last)
+    (void)hipStreamWaitEvent(s2, ev(h, EV_GRAM), 0);
+    (void)hipStreamWaitEvent(st, ev(h, EV_GRAM), 0);
+    launch_zero_upper_blocks(s2, h->bufA, ld, npad);
+  }
   double *A = h->bufA, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
@@ -379,7 +447,7 @@ static int factorize(gogp_handle *h) {
     if (mt2 > 0)
       launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
                       L + c2 * ld + c0, ld, pf);
-    order(h, EV_BASE + 2 * p, sp, s);  // panel p of L is final
+    order(h, EV_BASE + 4 * p, sp, s);  // panel p of L is final
     // the forward substitution step of this panel fills the panel stream's wait
     // for the next block column
     launch_trsv_fwd_step(sp, L, ld, h->Dinv, p, npanel, h->w, h->z);
@@ -389,7 +457,7 @@ static int factorize(gogp_handle *h) {
       // next block column first: A[c2:, c2:c2+256] -= L[c2:, c0:c2] * L[c2:c2+256, c0:c2]^T
       launch_dgemm_nt(s, GEMM_RECT, mt2, ntn, PANEL, -1.0, L + c2 * ld + c0, ld,
                       L + c2 * ld + c0, ld, 1.0, A + c2 * ld + c2, ld, pf);
-      order(h, EV_BASE + 2 * p + 1, s, sp);  // next panel may start
+      order(h, EV_BASE + 4 * p + 1, s, sp);  // next panel may start
       // the rest of the trailing matrix, lower tiles only
       if (mt2 > 2) {
         const int64_t c3 = c2 + PANEL;
@@ -397,6 +465,16 @@ static int factorize(gogp_handle *h) {
                         L + c3 * ld + c0, ld, 1.0, A + c3 * ld + c3, ld, pf);
       }
     }
+    // ---- fused sweep: step p of the triangular inverse right behind panel p ----------
+    if (eager) {
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * p), 0);
+      trtri_step(h, p, st, s2);
+    }
+  }
+  if (eager) {
+    (void)hipEventRecord(ev(h, EV_TRTRI), st);
+    h->trtri_done = true;
+    h->trtri_pending = true;
   }
   order(h, EV_FWD, sp, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
@@ -415,7 +493,10 @@ static int factorize(gogp_handle *h) {
   memcpy(&info, h->hscal + 8, sizeof info);
   if (info != 0) {
     (void)hipStreamSynchronize(sp);
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(s2);
     h->alpha_pending = false;
+    h->trtri_done = h->trtri_pending = false;
     h->notpd = (int64_t)info - 1;
     char buf[160];
     snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)",
@@ -470,7 +551,7 @@ extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
     h->factored = false;
     return GOGP_OK;
   }
-  rc = factorize(h);
+  rc = factorize(h, false);
   if (rc != GOGP_OK) return rc;
   rc = ensure_alpha(h);  // gp/gp.go:232-236
   if (rc != GOGP_OK) return rc;
@@ -492,7 +573,7 @@ static int observe_theta(gogp_handle *h, const double *x, double *lml) {
     if (lml) *lml = 0.0;
     return GOGP_OK;
   }
-  rc = factorize(h);  // gp/gp.go:402
+  rc = factorize(h, h->eager != 0);  // gp/gp.go:402 (always with gradient preparation)
   if (rc != GOGP_OK) return rc;
   h->observed = true;
   if (lml) *lml = h->lml;  // gp/gp.go:412
@@ -537,38 +618,25 @@ static int compute_kinv(gogp_handle *h) {
   if (h->have_kinv) return GOGP_OK;
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
-  hipStream_t sp = h->lookahead ? h->sp : h->s;
-  if (!h->bufY)
-    HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
-  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   GemmProfile *pf = &h->prof;
-  launch_set_identity_blocks(s, R, ld, npad);
-  order(h, EV_INIT, s, sp);
-  const int npanel = (int)(npad / PANEL);
-  for (int m = 0; m < npanel; ++m) {
-    const int64_t c0 = (int64_t)m * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    const double *Dm = h->Dinv + (size_t)m * PANEL * PANEL;
-    const int mr = (int)(c2 / TILE);  // block rows 0 .. c2
-    (void)c1;
-    // ---- column panel m of Y (panel stream): Y[0:c2, c0:c2] = R[0:c2, c0:c2] inv(L_mm)^T
-    launch_dgemm_nt(sp, GEMM_RECT, mr, 2, PANEL, 1.0, R + c0, ld, Dm, PANEL, 0.0, Y + c0, ld, pf);
-    order(h, EV_BASE + 2 * m, sp, s);
-    // ---- R[0:c2, c2:] -= Y[0:c2, c0:c2] * L[c2:, c0:c2]^T (main stream) ------------------
-    const int nt = (int)((npad - c2) / TILE);
-    if (nt > 0) {
-      const int ntn = nt < 2 ? nt : 2;
-      launch_dgemm_nt(s, GEMM_RECT, mr, ntn, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
-                      R + c2, ld, pf);
-      order(h, EV_BASE + 2 * m + 1, s, sp);  // next column panel of R is final
-      if (nt > 2) {
-        const int64_t c3 = c2 + PANEL;
-        launch_dgemm_nt(s, GEMM_RECT, mr, nt - 2, PANEL, -1.0, Y + c0, ld, L + c3 * ld + c0, ld,
-                        1.0, R + c3, ld, pf);
-      }
-    }
+  if (!h->trtri_done) {
+    // lazy path: the triangular inverse was not fused into the factorisation
+    hipStream_t sp = h->lookahead ? h->sp : h->s;
+    if (!h->bufY)
+      HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+    launch_zero_upper_blocks(s, h->bufA, ld, npad);
+    order(h, EV_INIT, s, sp);
+    const int npanel = (int)(npad / PANEL);
+    for (int m = 0; m < npanel; ++m) trtri_step(h, m, sp, s);
+    order(h, EV_TRTRI, sp, s);
+    h->trtri_done = true;
+  } else if (h->trtri_pending) {
+    (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
   }
-  // K^-1 (lower tiles) = Y Y^T, ragged K range; R is dead, write over it
-  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf);
+  h->trtri_pending = false;
+  // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
+  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, h->bufY, ld, h->bufY, ld, 0.0,
+                  h->bufA, ld, pf);
   h->have_kinv = true;
   return GOGP_OK;
 }
@@ -733,6 +801,8 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   h->observed = false;
   h->grad_valid = false;
   h->have_kinv = false;
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_done = h->trtri_pending = false;
   if (h->n == 0) return GOGP_OK;
   rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
@@ -798,6 +868,10 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (!h || !name) return GOGP_EARG;
   if (strcmp(name, "lookahead") == 0) {
     h->lookahead = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "eager") == 0) {
+    h->eager = value != 0;
     return GOGP_OK;
   }
   return fail(h, GOGP_EARG, "unknown option");

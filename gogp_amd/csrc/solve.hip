@@ -204,23 +204,44 @@ void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double
                      (long)ncols, dot, sq);
 }
 
-// R := upper block triangle (256-block rows) zero, identity on the diagonal.
-// One workgroup per 128-row x 1024-col strip keeps the stores full-line.
-__global__ __launch_bounds__(256) void identity_upper_kernel(double *__restrict__ R, long ld,
-                                                             long npad) {
+// Zero the STRICTLY upper 256-block triangle of a matrix: row r, columns
+// >= (r/256 + 1)*256.  This is where the right-hand side R of the triangular
+// inverse lives; the lower triangle + diagonal blocks (the Cholesky work area)
+// are not touched, so the two phases can share the buffer concurrently.
+__global__ __launch_bounds__(256) void zero_upper_kernel(double *__restrict__ R, long ld,
+                                                         long npad) {
   const long row = blockIdx.y;
-  const long cstart = (row / PANEL) * PANEL;  // first column of this row's diagonal 256-block
+  const long cstart = (row / PANEL + 1) * PANEL;
   const long c = cstart + ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (c >= npad) return;
   double2 v;
-  v.x = (c == row) ? 1.0 : 0.0;
-  v.y = (c + 1 == row) ? 1.0 : 0.0;
+  v.x = 0.0;
+  v.y = 0.0;
   *reinterpret_cast<double2 *>(R + row * ld + c) = v;
 }
 
-void launch_set_identity_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
-  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)npad);
-  hipLaunchKernelGGL(identity_upper_kernel, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
+  if (npad <= PANEL) return;
+  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
+  hipLaunchKernelGGL(zero_upper_kernel, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+}
+
+// Y[c0+i][c0+j] = Dinv[j][i]  (256x256 transpose of a diagonal-block inverse into
+// the diagonal block of Y = L^-T)
+__global__ __launch_bounds__(256) void ydiag_kernel(const double *__restrict__ Dinv,
+                                                    double *__restrict__ Y, long ld) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;  // 8x8 tiles of 32x32
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = Dinv[(by * 32 + ty + r) * 256 + bx * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) Y[(long)(bx * 32 + ty + r) * ld + by * 32 + tx] = tile[tx][ty + r];
+}
+
+void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld) {
+  hipLaunchKernelGGL(ydiag_kernel, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
 }
 
 __global__ void fill_kernel(double *p, long count, double v) {
