@@ -35,13 +35,29 @@ import numpy as np  # noqa: E402
 FP64_PEAK_TFLOPS = 78.6  # AMD public spec, fp64 matrix = vector
 
 
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota if there is one
+    (the GPU box shows 256 CPUs but grants 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
-    """Time the oracle's numpy/scipy twin on the first `sample_n` rows of the same
+    """Time the oracle's fast twin on the first `sample_n` rows of the same
     workload; returns the cpu_baseline object and the LML relative error of the
     GPU path on that same sample."""
-    from threadpoolctl import threadpool_info
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before the C oracle (libgomp) is loaded
+    from threadpoolctl import threadpool_limits
     from gogp_amd import kernel, synth
     from oracle.oracle import FastOracle  # checker / baseline only
+    threadpool_limits(limits=cores)
     X, y = synth.make_inputs(N, D, seed)
     Xs, ys = X[:sample_n], y[:sample_n]
     o = FastOracle(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, block=2048)
@@ -51,7 +67,7 @@ def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
     lml = o.Observe(x)
     g = o.Gradient()
     dt = time.time() - t0
-    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    threads = cores
     scale = (sample_n / float(N)) ** 3
     out = {
         "value": (1.0 / dt) * scale,
@@ -123,13 +139,16 @@ def main():
         lml, grad = step(args.warmup + k)
     sync()
     dt = time.perf_counter() - t0
-    gemm_ms, gemm_launches, gemm_flops = g.profile_read()
+    gemm_ms, gemm_launches, gemm_flops, gemm_busy_ms = g.profile_read()
     g.profile_enable(False)
     dt = gd.max_over_ranks(dt, device="cuda")
 
     if rank == 0:
         algo_flops_step = float(N) ** 3  # N^3/3 Cholesky + 2N^3/3 inverse
-        achieved = algo_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # The kernel's launches overlap (four streams): its busy time is the union of the
+        # event-timed launch intervals, not their sum.
+        achieved = (algo_flops_step * args.steps / (gemm_busy_ms * 1e-3) / 1e12
+                    if gemm_busy_ms > 0 else 0.0)
         try:
             peak_cal = G.mfma_f64_peak(20000, local_rank)
         except Exception:
@@ -166,12 +185,16 @@ def main():
                 "algorithmic_flops_per_step": algo_flops_step,
                 "launches_per_step": gemm_launches / max(1, args.steps),
                 "avg_launch_ms": gemm_ms / max(1, gemm_launches),
-                "kernel_ms_per_step": gemm_ms / max(1, args.steps),
+                "kernel_busy_ms_per_step": gemm_busy_ms / max(1, args.steps),
+                "sum_of_launch_durations_ms_per_step": gemm_ms / max(1, args.steps),
+                "launch_concurrency": gemm_ms / gemm_busy_ms if gemm_busy_ms > 0 else None,
                 "launched_flops_per_step": gemm_flops / max(1, args.steps),
                 "peak_calibrated_mfma_f64": peak_cal,
-                "note": "achieved = N^3 algorithmic flop per step / event-timed kernel time per step; "
-                        "peak = 78.6 TFLOP/s spec; peak_calibrated = sustained v_mfma_f64 issue-rate "
-                        "microbenchmark on this device",
+                "note": "achieved = N^3 algorithmic flop per step / HIP-event-timed busy time of the "
+                        "kernel per step (union of its launch intervals: launches overlap on 4 streams; "
+                        "rocprofv3 --stats sums them, see sum_of_launch_durations_ms_per_step = "
+                        "avg_launch_ms x launches_per_step); peak = 78.6 TFLOP/s spec; peak_calibrated = "
+                        "sustained v_mfma_f64 issue-rate microbenchmark on this device",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

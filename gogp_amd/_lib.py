@@ -42,7 +42,7 @@ SYMBOLS = [
     ("gogp_get_factor", ctypes.c_int, [_h, _dp]),
     ("gogp_set_factor", ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
     ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
-    ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp]),
+    ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
     ("gogp_version", ctypes.c_char_p, []),
     ("gogp_mfma_f64_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),

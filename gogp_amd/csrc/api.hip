@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <new>
+#include <utility>
 
 #include "common.h"
 
@@ -846,18 +847,39 @@ extern "C" int gogp_profile_enable(gogp_handle *h, int on) {
 }
 
 extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
-                                 double *gemm_flops) {
+                                 double *gemm_flops, double *gemm_busy_ms) {
   if (!h) return GOGP_EARG;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->s));
-  double ms = 0.0;
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  double ms = 0.0, busy = 0.0;
+  // launches run concurrently on up to four streams: besides the sum of the
+  // per-launch durations report the length of the UNION of the launch intervals
+  // (time during which at least one instance of the kernel is executing)
+  std::vector<std::pair<double, double>> iv;
+  iv.reserve(h->prof.used / 2);
   for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
-    float t = 0.f;
-    if (hipEventElapsedTime(&t, h->prof.pool[i], h->prof.pool[i + 1]) == hipSuccess) ms += t;
+    float t = 0.f, t0 = 0.f;
+    if (hipEventElapsedTime(&t, h->prof.pool[i], h->prof.pool[i + 1]) != hipSuccess) continue;
+    ms += t;
+    if (hipEventElapsedTime(&t0, h->prof.pool[0], h->prof.pool[i]) != hipSuccess) continue;
+    iv.emplace_back((double)t0, (double)t0 + (double)t);
   }
+  std::sort(iv.begin(), iv.end());
+  double cur_b = 0, cur_e = -1;
+  for (auto &p : iv) {
+    if (cur_e < cur_b || p.first > cur_e) {
+      if (cur_e >= cur_b) busy += cur_e - cur_b;
+      cur_b = p.first;
+      cur_e = p.second;
+    } else if (p.second > cur_e) {
+      cur_e = p.second;
+    }
+  }
+  if (cur_e >= cur_b && !iv.empty()) busy += cur_e - cur_b;
   if (gemm_ms) *gemm_ms = ms;
   if (gemm_launches) *gemm_launches = h->prof.launches;
   if (gemm_flops) *gemm_flops = h->prof.flops;
+  if (gemm_busy_ms) *gemm_busy_ms = busy;
   h->prof.used = 0;
   h->prof.flops = 0;
   h->prof.launches = 0;

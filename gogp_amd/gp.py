@@ -242,10 +242,11 @@ class GP:
         self._check(_lib.lib().gogp_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self):
-        ms, nl, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        """(sum of launch durations ms, launches, launched flops, union busy ms)"""
+        ms, nl, fl, bz = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
         self._check(_lib.lib().gogp_profile_read(self._h, ctypes.byref(ms), ctypes.byref(nl),
-                                                 ctypes.byref(fl)))
-        return ms.value, nl.value, fl.value
+                                                 ctypes.byref(fl), ctypes.byref(bz)))
+        return ms.value, nl.value, fl.value, bz.value
 
 
 class Model:

@@ -1,0 +1,125 @@
+// gogp.hpp -- C++ host-side mirror of the reference's gp.GP (gp/gp.go:20-38) over
+// the C ABI of include/gogp_hip.h.  Header-only; link with -lgogp_hip.
+//
+// The reference is Go (compiled code) and no Go toolchain exists in the build
+// image, so this header is the compiled-language host layer; the Go shim a
+// maintainer would add is in go/gogp/gp.go.  Method names,
+// argument meaning and error behaviour follow the reference: Absorb returns an
+// error code (gp/gp.go:228-230), Observe throws where the reference panics
+// (gp/gp.go:398-405), Produce returns false on error (gp/gp.go:338-340).
+#pragma once
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gogp_hip.h"
+
+namespace gogp {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+class GP {
+ public:
+  // Configuration (gp/gp.go:22-23)
+  int NDim;
+  gogp_desc desc;  // Simil + Noise in closed form (see gogp_desc)
+  // Data (gp/gp.go:26-28)
+  std::vector<double> ThetaSimil, ThetaNoise;
+  std::vector<std::vector<double>> X;
+  std::vector<double> Y;
+  bool Parallel = false;  // accepted for compatibility
+
+  explicit GP(const gogp_desc &d, int device = -1) : NDim(d.ndim), desc(d) {
+    if (gogp_create(&desc, device, &h_) != GOGP_OK)
+      throw Error(GOGP_EHIP, gogp_last_error(nullptr));
+    ThetaSimil.assign(desc.ntheta_simil, 0.0);  // gp/gp.go:50-56
+    ThetaNoise.assign(gogp_desc_ntheta_noise(&desc), 0.0);
+  }
+  ~GP() { gogp_destroy(h_); }
+  GP(const GP &) = delete;
+  GP &operator=(const GP &) = delete;
+
+  // gp/gp.go:80-87
+  int Absorb(const std::vector<std::vector<double>> &x, const std::vector<double> &y) {
+    X = x;
+    Y = y;
+    int rc = push();
+    if (rc != GOGP_OK) return rc;
+    double zero = 0.0;
+    return gogp_absorb(h_, ThetaSimil.data(), ThetaNoise.empty() ? &zero : ThetaNoise.data());
+  }
+
+  // gp/gp.go:244-253
+  double LML() {
+    double v = 0;
+    check(gogp_lml(h_, &v));
+    return v;
+  }
+
+  // gp/gp.go:258-360
+  bool Produce(const std::vector<std::vector<double>> &x, std::vector<double> &mu,
+               std::vector<double> &sigma) {
+    std::vector<double> flat = pack(x);
+    mu.assign(x.size(), 0.0);
+    sigma.assign(x.size(), 0.0);
+    return gogp_produce(h_, flat.data(), (int64_t)x.size(), mu.data(), sigma.data()) == GOGP_OK;
+  }
+
+  // gp/gp.go:374-413
+  double Observe(const std::vector<double> &x) {
+    const size_t P = ThetaSimil.size() + ThetaNoise.size();
+    if (x.size() < P) throw Error(GOGP_EARG, "len(x)");
+    double lml = 0;
+    if (x.size() == P) {
+      check(push());
+      check(gogp_observe(h_, x.data(), (int64_t)x.size(), &lml));
+    } else {
+      if ((x.size() - P) % (NDim + 1)) throw Error(GOGP_EARG, "len(x)");  // gp/gp.go:398-400
+      check(gogp_observe_full(h_, x.data(), (int64_t)x.size(), &lml));
+    }
+    for (size_t i = 0; i < ThetaSimil.size(); ++i) ThetaSimil[i] = std::exp(x[i]);
+    for (size_t i = 0; i < ThetaNoise.size(); ++i) ThetaNoise[i] = std::exp(x[ThetaSimil.size() + i]);
+    last_len_ = x.size();
+    return lml;
+  }
+
+  // gp/gp.go:418-499
+  std::vector<double> Gradient() {
+    std::vector<double> g(last_len_, 0.0);
+    check(gogp_gradient(h_, g.data(), (int64_t)g.size()));
+    return g;
+  }
+
+  // gp.GP.Alpha / gp.GP.L (gp/gp.go:35-36)
+  std::vector<double> Alpha() {
+    std::vector<double> a((size_t)gogp_n(h_));
+    check(gogp_get_alpha(h_, a.data()));
+    return a;
+  }
+
+  gogp_handle *handle() { return h_; }
+
+ private:
+  gogp_handle *h_ = nullptr;
+  size_t last_len_ = 0;
+
+  std::vector<double> pack(const std::vector<std::vector<double>> &x) const {
+    std::vector<double> flat(x.size() * (size_t)NDim);
+    for (size_t i = 0; i < x.size(); ++i)
+      for (int d = 0; d < NDim; ++d) flat[i * NDim + d] = x[i][d];
+    return flat;
+  }
+  int push() {
+    std::vector<double> flat = pack(X);
+    return gogp_set_data(h_, flat.data(), Y.data(), (int64_t)Y.size());
+  }
+  void check(int rc) {
+    if (rc != GOGP_OK) throw Error(rc, gogp_last_error(h_));
+  }
+};
+
+}  // namespace gogp

@@ -188,10 +188,12 @@ int gogp_set_factor(gogp_handle *h, const double *theta_simil,
  * kernel family (the fp64 MFMA GEMM/SYRK tile kernel) on the stream it is
  * launched on. */
 int gogp_profile_enable(gogp_handle *h, int on);
-/* Sum of event-measured durations (ms) and number of launches since the last
- * reset; resets the accumulators. */
+/* Since the last reset: sum of the event-measured launch durations (ms), number
+ * of launches, flops launched, and the length (ms) of the union of the launch
+ * intervals (launches overlap: the hot path runs on several streams).  Resets
+ * the accumulators. */
 int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
-                      double *gemm_flops);
+                      double *gemm_flops, double *gemm_busy_ms);
 
 /* Tuning knobs: name in {"lookahead","nb"}; returns GOGP_EARG if unknown. */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);

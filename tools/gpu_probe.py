@@ -35,11 +35,12 @@ for n in sizes:
         x = x0 + 0.01 * (k + 1)
         t = time.time(); lml = g.Observe(x); to.append(time.time() - t)
         t = time.time(); gr = g.Gradient(); tg.append(time.time() - t)
-    ms, nl, fl = g.profile_read()
+    ms, nl, fl, busy = g.profile_read()
     print("N=%d lml=%.6f grad=%s" % (n, lml, gr))
     print("  first: observe %.1f ms gradient %.1f ms" % (t_first * 1e3, t_gfirst * 1e3))
     print("  steady: observe %.2f ms gradient %.2f ms -> %.2f eval/s" % (
         min(to) * 1e3, min(tg) * 1e3, 1.0 / (min(to) + min(tg))))
-    print("  gemm kernel: %.2f ms/eval over %d launches/eval, %.2f TFLOP/s (launched flops), N^3=%.3e"
-          % (ms / 3, nl // 3, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, float(n) ** 3), flush=True)
+    print("  gemm kernel: sum %.2f ms/eval, busy(union) %.2f ms/eval over %d launches/eval; "
+          "N^3/busy = %.2f TFLOP/s" % (ms / 3, busy / 3, nl // 3,
+                                       float(n) ** 3 / (busy / 3 * 1e-3) / 1e12 if busy > 0 else 0), flush=True)
     g.close()
