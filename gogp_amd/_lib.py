@@ -46,6 +46,8 @@ SYMBOLS = [
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
     ("gogp_version", ctypes.c_char_p, []),
     ("gogp_mfma_f64_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
+    ("gogp_bench_gemm", ctypes.c_int,
+     [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_int, _dp, _dp]),
     ("gogp_test_diag256", ctypes.c_int,
      [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_uint64), _dp]),
     ("gogp_test_dgemm_nt", ctypes.c_int,

@@ -218,19 +218,25 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) {
-    // The main stream may be kept off a few CUs so that the panel stream's
-    // single-workgroup diagonal kernels never queue behind trailing-update tiles.
+    // The two big-update streams are kept off `reserve` CUs so that the panel
+    // stream's single-workgroup diagonal kernel (152 KB of LDS: it needs a whole
+    // CU) never waits for the GEMM streams to drain.
     const char *rs = getenv("GOGP_RESERVE_CUS");
-    const int reserve = rs ? atoi(rs) : 0;
+    const int reserve = rs ? atoi(rs) : 0;  // measured: any mask costs ~5 % GEMM throughput
     hipDeviceProp_t prop;
+    std::vector<uint32_t> mask;
     if (reserve > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
         reserve < prop.multiProcessorCount) {
       const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      mask.assign((ncu + 31) / 32, 0u);
       for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+    }
+    if (!mask.empty()) {
       e = hipExtStreamCreateWithCUMask(&h->s, (uint32_t)mask.size(), mask.data());
+      if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&h->s2, (uint32_t)mask.size(), mask.data());
     } else {
       e = hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking);
     }
   }
   if (e == hipSuccess) {
@@ -238,7 +244,6 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking);
   }
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
@@ -481,12 +486,20 @@ static int factorize(gogp_handle *h, bool eager) {
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
-  // backward substitution alpha = L^-T z on the panel stream: not needed for LML,
-  // overlaps whatever the main stream does next (the triangular inverse)
-  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
-  for (int b = npanel - 1; b >= 0; --b)
-    launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
-  (void)hipEventRecord(ev(h, EV_ALPHA), sp);
+  if (eager) {
+    // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
+    // triangular inverse is complete (st), instead of 64 dependent substitution steps
+    (void)hipStreamWaitEvent(st, ev(h, EV_FWD), 0);
+    launch_alpha_from_y(st, h->bufY, ld, h->z, npad, h->alpha);
+    (void)hipEventRecord(ev(h, EV_ALPHA), st);
+    (void)hipEventRecord(ev(h, EV_TRTRI), st);
+  } else {
+    // backward substitution alpha = L^-T z on the panel stream: not needed for LML
+    HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
+    for (int b = npanel - 1; b >= 0; --b)
+      launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
+    (void)hipEventRecord(ev(h, EV_ALPHA), sp);
+  }
   h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
@@ -979,5 +992,51 @@ extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, doub
   if (elapsed_us) *elapsed_us = ms * 1e3;
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dinfo); (void)hipFree(dst);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
+// Benchmark hook for the tile kernel: times `reps` launches of one GEMM shape on
+// device-resident pseudo-random operands (lda = ldb = K, ldc = nt*128).
+extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
+                               double *ms_per_launch, double *tflops) {
+  if (mt <= 0 || nt <= 0 || K <= 0 || K % GEMM_BK || reps <= 0 || mode < 0 || mode > 2)
+    return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  const int64_t M = (int64_t)mt * TILE, N = (int64_t)nt * TILE;
+  const int64_t Kld = (mode == GEMM_LAUUM) ? M : K;  // LAUUM: K range = matrix size
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipError_t e = hipMalloc(&dA, (size_t)M * Kld * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * Kld * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
+  if (e != hipSuccess) return GOGP_ENOMEM;
+  launch_fill(0, dA, M * Kld, 0.5);
+  launch_fill(0, dB, N * Kld, 0.25);
+  launch_fill(0, dC, M * N, 1.0);
+  GemmProfile pf;
+  pf.on = true;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
+  for (int w = 0; w < 2; ++w)
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, nullptr);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r)
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, &pf);
+  (void)hipEventRecord(e1, 0);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_launch) *ms_per_launch = ms / reps;
+  if (tflops) *tflops = pf.flops / (ms * 1e-3) / 1e12;
+  for (auto ev_ : pf.pool) (void)hipEventDestroy(ev_);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
   return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
 }

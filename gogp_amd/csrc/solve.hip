@@ -125,6 +125,37 @@ void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const doub
                      alpha);
 }
 
+// alpha = Y z with Y = L^-T upper triangular (row-major): alpha_i = sum_{q >= i0(i)} Y[i][q] z[q],
+// where i0 = first column of row i's 256-block (the block-lower part of Y is never
+// written).  One workgroup per 4 rows (one wave per row), 16-B loads.
+__global__ __launch_bounds__(256) void alpha_from_y_kernel(const double *__restrict__ Y, long ld,
+                                                           const double *__restrict__ z, long npad,
+                                                           double *__restrict__ alpha) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 4 + wid;
+  if (i >= npad) return;
+  const long q0 = (i / PANEL) * PANEL;
+  const double *row = Y + i * ld;
+  double s0 = 0.0, s1 = 0.0;
+  for (long q = q0 + lane * 2; q < npad; q += 128) {
+    const double2 y = *reinterpret_cast<const double2 *>(row + q);
+    const double2 zz = *reinterpret_cast<const double2 *>(z + q);
+    s0 += y.x * zz.x;
+    s1 += y.y * zz.y;
+  }
+  double s = s0 + s1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) alpha[i] = s;
+}
+
+void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
+                         int64_t npad, double *alpha) {
+  if (npad <= 0) return;
+  hipLaunchKernelGGL(alpha_from_y_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
+                     (long)ld, z, (long)npad, alpha);
+}
+
 // scalars[0] = sum_{i<n} 2 log L_ii ; scalars[1] = sum_{i<n} z_i^2 ;
 // scalars[2] = sum_{i<n} y_i alpha_i (only if alpha != nullptr)
 __global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restrict__ L, long ld,

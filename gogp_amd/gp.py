@@ -308,3 +308,12 @@ def diag256_check(A: np.ndarray, device: int = -1):
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "test_diag256")
     return L, X, np.array(list(st), dtype=np.uint64), us.value
+
+
+def bench_gemm(mode: int, mt: int, nt: int, K: int, reps: int = 5, device: int = -1):
+    """Time the tile kernel on one shape: returns (ms per launch, TFLOP/s)."""
+    ms, tf = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = _lib.lib().gogp_bench_gemm(device, mode, mt, nt, K, reps, ctypes.byref(ms), ctypes.byref(tf))
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "bench_gemm")
+    return ms.value, tf.value

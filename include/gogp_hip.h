@@ -215,6 +215,12 @@ int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mf
 int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
                        const double *A, const double *B, double beta, double *C);
 
+/* Benchmark hook for the tile kernel: `reps` launches of one shape (mode 0 RECT
+ * mt x nt tiles, 1 LOWER mt x mt, 2 LAUUM mt x mt with K = mt*128) on device
+ * buffers; returns ms per launch and TFLOP/s on the flops launched. */
+int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
+                    double *ms_per_launch, double *tflops);
+
 /* Diagnostic hook for the diagonal-block kernel: factor + invert one 256x256 SPD
  * block given on the host (row-major, lower triangle used); returns the factor,
  * its dense inverse, 24 in-kernel s_memtime stamps of a diagnostic build and the

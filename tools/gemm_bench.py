@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gogp_amd import gp as G
+print("peak: %.1f TF" % G.mfma_f64_peak(50000))
+for name, mode, mt, nt, K in [
+    ("RECT 64x64 K=256", 0, 64, 64, 256), ("RECT 64x64 K=512", 0, 64, 64, 512),
+    ("RECT 64x64 K=1024", 0, 64, 64, 1024), ("RECT 64x64 K=4096", 0, 64, 64, 4096),
+    ("LOWER 120 K=256", 1, 120, 120, 256), ("LOWER 120 K=512", 1, 120, 120, 512),
+    ("LOWER 64 K=256", 1, 64, 64, 256), ("LOWER 32 K=256", 1, 32, 32, 256),
+    ("RECT 32x96 K=256", 0, 32, 96, 256), ("RECT 96x32 K=256", 0, 96, 32, 256),
+    ("RECT 126x2 K=256", 0, 126, 2, 256), ("RECT 64x2 K=256", 0, 64, 2, 256), ("RECT 16x2 K=256", 0, 16, 2, 256),
+    ("LAUUM 128", 2, 128, 128, 0),
+]:
+    ms, tf = G.bench_gemm(mode, mt, nt, K if K else 16, reps=5)
+    print("%-22s %8.3f ms  %6.2f TFLOP/s" % (name, ms, tf), flush=True)
