@@ -665,10 +665,6 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
   if (len != grad_len(h)) return fail(h, GOGP_EARG, "gradient: wrong length");
   for (int64_t i = 0; i < len; ++i) grad[i] = 0.0;
   if (h->n == 0) return GOGP_OK;  // gp/gp.go:427-430
-  if (h->with_obs)
-    return fail(h, GOGP_EARG,
-                "gradient w.r.t. inputs/outputs (full Observe form) is not implemented on "
-                "the device path yet");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->grad_valid) {
     int rc = compute_kinv(h);
@@ -698,6 +694,23 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
     h->grad_valid = true;
   }
   for (int i = 0; i < h->P; ++i) grad[i] = h->grad_cache[i];
+  if (h->with_obs) {
+    // gp/gp.go:118-129 (inputs) and :488-493 (outputs: -alpha)
+    hipStream_t s = h->s;
+    const int64_t n = h->n;
+    double *gx = nullptr;
+    HIPCHK(h, hipMalloc(&gx, (size_t)h->npad * h->D * sizeof(double)));
+    launch_xgrad(s, h->devP, h->D, h->dX, h->alpha, h->bufA, h->npad, n, h->npad, gx);
+    hipError_t e = hipMemcpyAsync(grad + h->P, gx, (size_t)n * h->D * sizeof(double),
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(grad + h->P + n * h->D, h->alpha, (size_t)n * sizeof(double),
+                         hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(gx);
+    HIPCHK(h, e);
+    for (int64_t i = 0; i < n; ++i) grad[h->P + n * h->D + i] = -grad[h->P + n * h->D + i];
+  }
   return GOGP_OK;
 }
 

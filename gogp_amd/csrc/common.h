@@ -101,6 +101,12 @@ void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dim
                         const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
                         int64_t npad, double *partials, double *out);
 
+// gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
+// gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}
+void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                  const double *alpha, double *Kinv, int64_t ld, int64_t n, int64_t npad,
+                  double *gx);
+
 // dot_j = sum_i V[j][i] vec_i ; sq_j = sum_i V[j][i]^2  (either output may be null)
 void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double *vec,
                         int64_t ncols, int64_t m, double *dot, double *sq);

@@ -140,4 +140,107 @@ void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dim
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
 }
 
+// ---- gradient w.r.t. the inputs (full Observe form) ------------------------------
+// gp/gp.go:118-129 builds one dense dK per input coordinate (N*D matrices of N x N);
+// since dK^{(i,d)} has only row/column i non-zero,
+//     dLML/dx_{i,d} = 1/2 tr(W dK^{(i,d)}) = sum_j W_ij dk(x_i,x_j)/dx_{i,d},
+// one pass over the FULL symmetric W = alpha alpha^T - K^-1 (the lower triangle of
+// K^-1 is mirrored first).  One workgroup per 64 rows; 4 threads share a row and
+// split each 64-column tile; fixed-order reductions.
+
+// upper 32x32 tiles <- transpose of the lower ones (diagonal 128-blocks are
+// already full from the LAUUM tile kernel)
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ A, long ld, int nt32) {
+  __shared__ double tile[32][33];
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  if (ti == tj || ti >= nt32) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = A[(long)(ti * 32 + ty + r) * ld + tj * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) A[(long)(tj * 32 + ty + r) * ld + ti * 32 + tx] = tile[tx][ty + r];
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void xgrad_kernel(const DevParams *__restrict__ Pp,
+                                                    const double *__restrict__ X,
+                                                    const double *__restrict__ alpha,
+                                                    const double *__restrict__ Kinv, long ld,
+                                                    long n, long npad, double *__restrict__ gx) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Xi = sm;               // [64][D]
+  double *Xj = Xi + 64 * D;      // [64][D]
+  double *T = Xj + 64 * D;       // [64][65]  W tile
+  double *aj = T + 64 * 65;      // [64]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * 64;
+  const int r = tid >> 2, q = tid & 3;
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int rr = idx / D, d = idx - rr * D;
+    Xi[idx] = (r0 + rr < n) ? X[(r0 + rr) * D + d] : 0.0;
+  }
+  const double ai = (r0 + r < n) ? alpha[r0 + r] : 0.0;
+  double acc[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) acc[d] = 0.0;
+  const double *xi = Xi + r * D;
+  for (long c0 = 0; c0 < npad; c0 += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int rr = idx / D, d = idx - rr * D;
+      Xj[idx] = (c0 + rr < n) ? X[(c0 + rr) * D + d] : 0.0;
+    }
+    if (tid < 64) aj[tid] = (c0 + tid < n) ? alpha[c0 + tid] : 0.0;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int rr = idx >> 6, cc = idx & 63;
+      T[rr * 65 + cc] = Kinv[(r0 + rr) * ld + c0 + cc];
+    }
+    __syncthreads();
+    if (r0 + r < n) {
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = q * 16 + jj;
+        if (c0 + j < n && c0 + j != r0 + r) {
+          const double W = ai * aj[j] - T[r * 65 + j];
+          const double *xj = Xj + j * D;
+          simil_xgrad_accum<DMAX>(
+              P, [&](int d) { return xi[d]; }, [&](int d) { return xj[d]; }, W, acc);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    double v = acc[d];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    if (q == 0 && d < D && r0 + r < n) gx[(r0 + r) * D + d] = v;
+  }
+}
+
+void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                  const double *alpha, double *Kinv, int64_t ld, int64_t n, int64_t npad,
+                  double *gx) {
+  const int nt32 = (int)(npad / 32);
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, s, Kinv,
+                     (long)ld, nt32);
+  const size_t lds = (size_t)(128 * ndim + 64 * 65 + 64) * sizeof(double);
+  const dim3 grid((unsigned)(npad / 64));
+#define GOGP_LAUNCH_XG(DM)                                                                   \
+  hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
+                     (long)n, (long)npad, gx)
+  if (ndim <= 4) GOGP_LAUNCH_XG(4);
+  else if (ndim <= 8) GOGP_LAUNCH_XG(8);
+  else if (ndim <= 16) GOGP_LAUNCH_XG(16);
+  else if (ndim <= 32) GOGP_LAUNCH_XG(32);
+  else GOGP_LAUNCH_XG(64);
+#undef GOGP_LAUNCH_XG
+}
+
 }  // namespace gogp

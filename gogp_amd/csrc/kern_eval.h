@@ -133,4 +133,52 @@ __device__ __forceinline__ void simil_grad_accum(const DevParams &P, FA xa, FB x
   }
 }
 
+// Accumulate  W * dk(xa, xb)/dxa_d  into acc[d]  (d < ndim <= DMAX): the
+// derivative the AD tape yields for the first input (gp/gp.go:118-123).  For the
+// stationary kernels here dk/dxb = -dk/dxa.
+template <int DMAX, class FA, class FB>
+__device__ __forceinline__ void simil_xgrad_accum(const DevParams &P, FA xa, FB xb, double W,
+                                                  double *acc) {
+  const int D = P.ndim;
+  for (int t = 0; t < P.nterms; ++t) {
+    const int kind = P.kind[t];
+    const double c = P.c[t];
+    if (kind == GOGP_K_PERIODIC) {
+      const double w = P.w[t];
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double dd = sin(w * fabs(xa(d) - xb(d))) * P.inv_len[t][d];
+        s += dd * dd;
+      }
+      const double cf = W * c * exp(-2.0 * s) * (-4.0) * w;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d)
+        if (d < D) {
+          const double dx = xa(d) - xb(d);
+          const double phi = w * fabs(dx);
+          double sn, cs;
+          sincos(phi, &sn, &cs);
+          const double il = P.inv_len[t][d];
+          const double sg = dx > 0.0 ? 1.0 : (dx < 0.0 ? -1.0 : 0.0);
+          acc[d] += cf * (sn * il) * cs * il * sg;
+        }
+    } else {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double u = (xa(d) - xb(d)) * P.inv_len[t][d];
+        s += u * u;
+      }
+      double f, dfdr2;
+      radial_eval(kind, s, f, dfdr2);
+      const double g = W * c * dfdr2 * 2.0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d)
+        if (d < D) {
+          const double il = P.inv_len[t][d];
+          acc[d] += g * (xa(d) - xb(d)) * il * il;
+        }
+    }
+  }
+}
+
 }  // namespace gogp

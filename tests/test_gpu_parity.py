@@ -94,6 +94,14 @@ def test_elemental_model_known_answers(gpmod, known):
         g = gpmod.GP(1, kernel.Normal, _noise(c["noise"]))
         ll = g.Observe(x)  # full form: inputs and outputs carried in x
         assert abs(ll - c["ll"]) < 1e-6, c["name"]
+        dll = g.Gradient()
+        assert len(dll) == len(x)  # gp_test.go:237
+        # every component against a forward difference, as gp_test.go:242-252
+        dx, eps = known["fd"]["dx"], known["fd"]["eps"]
+        for j in range(len(x)):
+            xj = x.copy()
+            xj[j] += dx
+            assert abs(dll[j] - (g.Observe(xj) - ll) / dx) <= eps, (c["name"], j)
         P = g._ns + g._nn
         n = (len(x) - P) // 2
         # hyperparameters-only form (gp_test.go:254-267)
@@ -188,6 +196,51 @@ def test_config2_n4096_d4(gpmod):
     D = 4
     _check_against(gpmod, FastOracle, "config2", D, kernel.Scaled(kernel.Normal), kernel.UniformNoise,
                    [1.0, math.sqrt(D / 6.0)], [0.1], n=4096, m=256, seed=20251115)
+
+
+@pytest.mark.parametrize("name,D,simil,noise,ts,tn", [c for c in CASES if c[0] in (
+    "scaled_rbf", "ard_rbf", "matern32", "matern52_ref", "periodic", "hyperpriors")],
+    ids=lambda v: v if isinstance(v, str) else None)
+def test_full_form_gradient_vs_faithful_oracle(gpmod, name, D, simil, noise, ts, tn):
+    """Observe with inputs and outputs carried in x (gp/gp.go:366-369): gradient
+    w.r.t. hyperparameters, every input coordinate and every output
+    (gp/gp.go:118-129,488-493) against the faithful oracle's dense-dK gradient."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(17)
+    n = 37
+    X, y = _data(rng, n, D)
+    x = np.concatenate([np.log(np.array(list(ts) + list(tn))), X.reshape(-1), y])
+    g = gpmod.GP(D, simil, noise)
+    o = Oracle(D, simil, noise)
+    lml, lml_o = g.Observe(x), o.Observe(x)
+    assert abs(lml - lml_o) <= 1e-8 * max(1.0, abs(lml_o))
+    grad, grad_o = g.Gradient(), o.Gradient()
+    assert grad.shape == grad_o.shape == x.shape
+    scale = max(1.0, np.abs(grad_o).max())
+    assert np.abs(grad - grad_o).max() <= 1e-6 * scale, (name, np.abs(grad - grad_o).argmax())
+    np.testing.assert_array_equal(g.X, X)  # gp/gp.go:391-396: X, Y re-sliced from x
+    np.testing.assert_array_equal(g.Y, y)
+
+
+def test_full_form_gradient_mid_size(gpmod):
+    """Input/output gradient at a size that spans several 64-row tiles and 256-panels,
+    against central differences of the HIP LML itself on a few coordinates."""
+    rng = np.random.default_rng(23)
+    n, D = 300, 3
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    x = np.concatenate([np.log([1.1, 0.6, 0.2]), X.reshape(-1), y])
+    g = gpmod.GP(D, simil, noise)
+    g.Observe(x)
+    grad = g.Gradient()
+    np.testing.assert_allclose(grad[3 + n * D:], -g.Alpha, rtol=1e-12, atol=1e-14)
+    for j in [0, 1, 2, 3, 3 + 5, 3 + n * D - 1, 3 + 137 * D + 1, 3 + n * D + 7]:
+        h = 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[j] += h
+        xm[j] -= h
+        fd = (g.Observe(xp) - g.Observe(xm)) / (2 * h)
+        assert abs(fd - grad[j]) <= 1e-5 * max(1.0, abs(fd)), (j, fd, grad[j])
 
 
 def test_absorb_then_produce_and_restore(gpmod):
