@@ -62,6 +62,7 @@ struct gogp_handle {
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
+  int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
   int eager = 1;               // Observe also runs the triangular inverse (gradient
                                // preparation), interleaved with the Cholesky sweep
   bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
@@ -372,35 +373,50 @@ static void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
 }
 
 // ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
-// One step of the triangular inverse Y = L^-T (upper), column panel m:
-//   Y[c0:c2, c0:c2] = inv(L_mm)^T ;  Y[0:c0, c0:c2] = R[0:c0, c0:c2] inv(L_mm)^T      (chain, st)
-//   R[0:c2, c2:]   -= Y[0:c2, c0:c2] L[c2:, c0:c2]^T                                  (updates, s2)
+// One super-step of the triangular inverse Y = L^-T (upper): column panels
+// P0 .. P0+nsub-1 (256 wide each), then ONE rank-(nsub*256) update of everything
+// to the right:
+//   per sub-panel p:  Y[c0:c2, c0:c2] = inv(L_pp)^T ;  Y[0:c0, c0:c2] = R[0:c0, c0:c2] inv(L_pp)^T
+//                     R[0:c2, c2:CE] -= Y[0:c2, c0:c2] L[c2:CE, c0:c2]^T      (inside the super-panel)
+//   R[0:CE, CE:]   -= Y[0:CE, C0:CE] L[CE:, C0:CE]^T                          (updates, s2)
 // R occupies the strictly upper 256-block triangle of bufA (zero-initialised),
-// which the Cholesky sweep never touches: step m only needs panel m of L and its
-// diagonal inverse, so it can run right behind the factorisation of panel m.
-static void trtri_step(gogp_handle *h, int m, hipStream_t st, hipStream_t s2) {
+// which the Cholesky sweep never touches: the step only needs the panels of L it
+// names and their diagonal inverses, so it runs right behind their factorisation.
+static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hipStream_t s2) {
   const int64_t npad = h->npad, ld = npad;
   double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   GemmProfile *pf = &h->prof;
-  const int64_t c0 = (int64_t)m * PANEL, c2 = c0 + PANEL;
-  const double *Dm = h->Dinv + (size_t)m * PANEL * PANEL;
-  const int mr = (int)(c2 / TILE);
-  if (m > 0 && st != s2) (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (m - 1) + 3), 0);
-  launch_ydiag(st, Dm, Y + c0 * ld + c0, ld);
-  if (m > 0)
-    launch_dgemm_nt(st, GEMM_RECT, mr - 2, 2, PANEL, 1.0, R + c0, ld, Dm, PANEL, 0.0, Y + c0, ld,
-                    pf);
-  order(h, EV_BASE + 4 * m + 2, st, s2);
-  const int nt = (int)((npad - c2) / TILE);
+  const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
+  // R[0:C0, C0:CE] is final once the previous super-step's next-columns update is done
+  if (P0 > 0 && st != s2)
+    (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (P0 - h->superpanel) + 3), 0);
+  for (int q = 0; q < nsub; ++q) {
+    const int p = P0 + q;
+    const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
+    const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+    launch_ydiag(st, Dp, Y + c0 * ld + c0, ld);
+    if (c2 < CE)  // block below the diagonal inside the super-panel: part of the K range
+      launch_zero_block(st, Y + c2 * ld + c0, ld, CE - c2, PANEL);
+    if (c0 > 0)
+      launch_dgemm_nt(st, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
+                      Y + c0, ld, pf);
+    if (c2 < CE)
+      launch_dgemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
+                      Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
+  }
+  order(h, EV_BASE + 4 * P0 + 2, st, s2);
+  const int nt = (int)((npad - CE) / TILE);
   if (nt > 0) {
-    const int ntn = nt < 2 ? nt : 2;
-    launch_dgemm_nt(s2, GEMM_RECT, mr, ntn, PANEL, -1.0, Y + c0, ld, L + c2 * ld + c0, ld, 1.0,
-                    R + c2, ld, pf);
-    (void)hipEventRecord(ev(h, EV_BASE + 4 * m + 3), s2);
-    if (nt > 2) {
-      const int64_t c3 = c2 + PANEL;
-      launch_dgemm_nt(s2, GEMM_RECT, mr, nt - 2, PANEL, -1.0, Y + c0, ld, L + c3 * ld + c0, ld,
-                      1.0, R + c3, ld, pf);
+    const int64_t Kw = CE - C0;
+    const int mr = (int)(CE / TILE);
+    const int ntn = nt < 2 * h->superpanel ? nt : 2 * h->superpanel;  // next super-panel's columns
+    launch_dgemm_nt(s2, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
+                    R + CE, ld, pf);
+    (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);
+    if (nt > ntn) {
+      const int64_t C3 = CE + (int64_t)ntn * TILE;
+      launch_dgemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
+                      R + C3, ld, pf);
     }
   }
 }
@@ -435,46 +451,66 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipStreamWaitEvent(s2, ev(h, EV_GRAM), 0);
     (void)hipStreamWaitEvent(st, ev(h, EV_GRAM), 0);
     launch_zero_upper_blocks(s2, h->bufA, ld, npad);
+    order(h, EV_INIT, s2, st);  // st also writes R (updates inside a super-panel)
   }
   double *A = h->bufA, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
+  const int SW = h->superpanel;
   // working copy of y for the forward substitution (runs on the panel stream)
   HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
-  for (int p = 0; p < npanel; ++p) {
-    const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-    (void)c1;
-    // ---- panel factorisation (panel stream) ---------------------------------------
-    // 256x256 diagonal block: factor + dense inverse, one workgroup
-    launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
-    const int mt2 = (int)((npad - c2) / TILE);
-    // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
-    if (mt2 > 0)
-      launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
-                      L + c2 * ld + c0, ld, pf);
-    order(h, EV_BASE + 4 * p, sp, s);  // panel p of L is final
-    // the forward substitution step of this panel fills the panel stream's wait
-    // for the next block column
-    launch_trsv_fwd_step(sp, L, ld, h->Dinv, p, npanel, h->w, h->z);
-    // ---- trailing update, rank 256 (main stream) ------------------------------------
-    if (mt2 > 0) {
-      const int ntn = mt2 < 2 ? mt2 : 2;
-      // next block column first: A[c2:, c2:c2+256] -= L[c2:, c0:c2] * L[c2:c2+256, c0:c2]^T
-      launch_dgemm_nt(s, GEMM_RECT, mt2, ntn, PANEL, -1.0, L + c2 * ld + c0, ld,
-                      L + c2 * ld + c0, ld, 1.0, A + c2 * ld + c2, ld, pf);
-      order(h, EV_BASE + 4 * p + 1, s, sp);  // next panel may start
+  // Right-looking blocked Cholesky in super-panels of SW 256-wide panels: the
+  // dependency chain (diagonal blocks, panel solves, updates inside the
+  // super-panel) runs on the panel stream with 256-wide steps; the trailing
+  // matrix gets ONE rank-(SW*256) update per super-panel on the main stream
+  // (next super-panel's block columns first: look-ahead).
+  for (int P0 = 0; P0 < npanel; P0 += SW) {
+    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
+    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
+    for (int q = 0; q < nsub; ++q) {
+      const int p = P0 + q;
+      const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
+      double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+      // 256x256 diagonal block: factor + dense inverse, one workgroup
+      launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+      const int mt2 = (int)((npad - c2) / TILE);
+      // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
+      if (mt2 > 0)
+        launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
+                        L + c2 * ld + c0, ld, pf);
+      // remaining block columns of this super-panel, each from its own diagonal block
+      // down (the blocks above belong to R of the fused triangular inverse):
+      // A[cr:, cr:cr+256] -= L[cr:, c0:c2] L[cr:cr+256, c0:c2]^T
+      for (int64_t cr = c2; cr < CE; cr += PANEL)
+        launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0, L + cr * ld + c0,
+                        ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
+    }
+    order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
+    // the forward substitution steps of these panels fill the panel stream's wait
+    // for the next block columns
+    for (int q = 0; q < nsub; ++q)
+      launch_trsv_fwd_step(sp, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
+    // ---- trailing update, rank nsub*256 (main stream) ----------------------------------
+    const int mtE = (int)((npad - CE) / TILE);
+    if (mtE > 0) {
+      const int64_t Kw = CE - C0;
+      const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
+      // next super-panel's block columns first, each from its diagonal block down
+      for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
+        launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0, ld,
+                        L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      order(h, EV_BASE + 4 * P0 + 1, s, sp);  // next super-panel may start
       // the rest of the trailing matrix, lower tiles only
-      if (mt2 > 2) {
-        const int64_t c3 = c2 + PANEL;
-        launch_dgemm_nt(s, GEMM_LOWER, mt2 - 2, mt2 - 2, PANEL, -1.0, L + c3 * ld + c0, ld,
-                        L + c3 * ld + c0, ld, 1.0, A + c3 * ld + c3, ld, pf);
+      if (mtE > ntn) {
+        const int64_t C3 = CE + (int64_t)ntn * TILE;
+        launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
+                        L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
       }
     }
-    // ---- fused sweep: step p of the triangular inverse right behind panel p ----------
+    // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * p), 0);
-      trtri_step(h, p, st, s2);
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
+      trtri_superstep(h, P0, nsub, st, s2);
     }
   }
   if (eager) {
@@ -641,7 +677,8 @@ static int compute_kinv(gogp_handle *h) {
     launch_zero_upper_blocks(s, h->bufA, ld, npad);
     order(h, EV_INIT, s, sp);
     const int npanel = (int)(npad / PANEL);
-    for (int m = 0; m < npanel; ++m) trtri_step(h, m, sp, s);
+    for (int P0 = 0; P0 < npanel; P0 += h->superpanel)
+      trtri_superstep(h, P0, (npanel - P0 < h->superpanel) ? npanel - P0 : h->superpanel, sp, s);
     order(h, EV_TRTRI, sp, s);
     h->trtri_done = true;
   } else if (h->trtri_pending) {
@@ -920,6 +957,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   }
   if (strcmp(name, "eager") == 0) {
     h->eager = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "superpanel") == 0) {
+    if (value < 1 || value > 4) return fail(h, GOGP_EARG, "superpanel must be 1..4");
+    h->superpanel = (int)value;
     return GOGP_OK;
   }
   return fail(h, GOGP_EARG, "unknown option");

@@ -114,6 +114,7 @@ void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double
 void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad);
 void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha);
+void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n,

@@ -275,6 +275,23 @@ void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld) 
   hipLaunchKernelGGL(ydiag_kernel, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
 }
 
+// zero a rows x cols block (cols a multiple of 2, 16-B aligned)
+__global__ __launch_bounds__(256) void zero_block_kernel(double *__restrict__ B, long ld, long cols) {
+  const long r = blockIdx.y;
+  const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= cols) return;
+  double2 v;
+  v.x = 0.0;
+  v.y = 0.0;
+  *reinterpret_cast<double2 *>(B + r * ld + c) = v;
+}
+
+void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return;
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(zero_block_kernel, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
+}
+
 __global__ void fill_kernel(double *p, long count, double v) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (long)gridDim.x * blockDim.x)

@@ -333,3 +333,48 @@ def test_barebones_csv_config1(gpmod, golden_dir):
     x = np.zeros(3)
     assert abs(g.Observe(x) - o.Observe(x)) < 1e-9
     np.testing.assert_allclose(g.Gradient(), o.Gradient(), rtol=1e-8, atol=1e-9)
+
+
+def test_config3_full_size_properties(gpmod):
+    """BASELINE config 3 (N=16384, D=8, RBF + white noise, fp64) at FULL size through
+    size-independent properties (the oracle does not finish in seconds at this N):
+      1. K alpha = y on sampled rows (K rows rebuilt on the host from the kernel formula);
+      2. the gradient agrees with a central difference of LML along a random direction;
+      3. Produce at the training inputs: mu_i = y_i - s2 alpha_i exactly (K alpha = y), and
+         sum_i sigma_i^2 = N s2 - s2^2 tr(K^-1), with tr(K^-1) taken from the noise component
+         of the gradient (dLML/dlog s = s2 (alpha.alpha - tr K^-1)) -- a checksum tying
+         Absorb/Observe, Gradient and Produce together."""
+    from gogp_amd import synth
+    N, D = 16384, 8
+    X, y = synth.make_inputs(N, D, 20251116)
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    th = synth.theta0(D)
+    x = np.log(th)
+    lml = g.Observe(x)
+    grad = g.Gradient()
+    alpha = g.Alpha
+    c, l, s = th
+    s2 = s * s
+    # 1. K alpha = y on sampled rows
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, N, 24):
+        r2 = ((X[i] - X) ** 2).sum(1) / (l * l)
+        krow = c * np.exp(-0.5 * r2)
+        krow[i] += s2
+        assert abs(krow @ alpha - y[i]) <= 1e-8 * max(1.0, np.abs(krow * alpha).sum()), i
+    # 2. directional derivative
+    v = rng.normal(size=3)
+    v /= np.linalg.norm(v)
+    h = 1e-4
+    fd = (g.Observe(x + h * v) - g.Observe(x - h * v)) / (2 * h)
+    assert abs(fd - grad @ v) <= 1e-6 * max(1.0, abs(fd)), (fd, grad @ v)
+    # 3. Produce at the training inputs
+    g.Observe(x)
+    mu, sigma = g.Produce(X)
+    np.testing.assert_allclose(mu, y - s2 * alpha, rtol=0, atol=1e-8 * max(1.0, np.abs(y).max()))
+    tr_kinv = float(alpha @ alpha) - grad[2] / s2
+    want = N * s2 - s2 * s2 * tr_kinv
+    got = float((sigma ** 2).sum())
+    assert abs(got - want) <= 1e-6 * abs(want), (got, want)
+    assert np.isfinite(lml)
