@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--nobs", type=int, default=16384)
+    ap.add_argument("--ndim", type=int, default=8)
     ap.add_argument("--cpu-sample-n", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,13 +103,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # one process per GPU; GOGP_DIST_BACKEND=gloo lets several ranks share one GPU for
+    # rehearsals on a 1-GPU box (RCCL refuses duplicate devices)
+    backend = os.environ.get("GOGP_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     from gogp_amd import dist as gd
     from gogp_amd import kernel, synth
     from gogp_amd import gp as G
-    gd.init("nccl", torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+    gd.init(backend, torch.device("cuda", local_rank))
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    N, D = args.n, args.d
+    N, D = args.nobs, args.ndim
     seed = 20251114 + 2  # seed = 20251114 + config index
     X, y = synth.make_inputs(N, D, seed)
     simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
@@ -141,7 +146,7 @@ def main():
     dt = time.perf_counter() - t0
     gemm_ms, gemm_launches, gemm_flops, gemm_busy_ms = g.profile_read()
     g.profile_enable(False)
-    dt = gd.max_over_ranks(dt, device="cuda")
+    dt = gd.max_over_ranks(dt, device=red_dev)
 
     if rank == 0:
         algo_flops_step = float(N) ** 3  # N^3/3 Cholesky + 2N^3/3 inverse

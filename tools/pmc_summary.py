@@ -1,0 +1,28 @@
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel family."""
+import collections, csv, glob, sys
+
+def short(n):
+    for k in ['dgemm_nt_kernel<0, 64>', 'dgemm_nt_kernel<1, 64>', 'dgemm_nt_kernel<0, 128>', 'dgemm_nt_kernel<1, 128>',
+              'dgemm_nt_kernel<2, 128>', 'diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y',
+              'zero_upper', 'mfma_f64_peak']:
+        if k in n:
+            return k
+    return None
+
+for path in sys.argv[1:]:
+    f = glob.glob(path + "/*/*_counter_collection.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    if not rows:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(set)
+    dur = {}
+    for r in rows:
+        k = short(r['Kernel_Name'])
+        if not k:
+            continue
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        cnt[k].add(r['Dispatch_Id'])
+    print("==", path)
+    for k in agg:
+        print("  %-26s dispatches=%5d  " % (k, len(cnt[k])) + "  ".join("%s=%.4g" % kv for kv in sorted(agg[k].items())))
