@@ -58,6 +58,10 @@ struct gogp_handle {
   hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
   hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
                              // skinny updates, substitution steps -- overlaps the big updates
+  hipStream_t sl = nullptr;  // early part of K^-1 = Y Y^T (split LAUUM) during the sweep's tail
+  int lauum_split_pct = 0;   // K range [0, pct% of N) of LAUUM summed during the sweep; 0 = off
+                             // (measured: no gain, the sweep is already throughput-bound)
+  int64_t lauum_ksplit = 0;  // columns already summed by the early part (this evaluation)
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
@@ -178,7 +182,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->sp, h->s2, h->st}) {
+  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) {
     if (q) (void)hipStreamSynchronize(q);
     if (q) (void)hipStreamDestroy(q);
   }
@@ -245,6 +249,7 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->sl, hipStreamNonBlocking, least);
   }
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
@@ -296,7 +301,7 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   HIPCHK(h, hipSetDevice(h->device));
   // nothing of a previous evaluation may still be running when buffers are
   // replaced or re-filled
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_pending = h->alpha_pending = false;
   int rc = ensure_n(h, n);
   if (rc != GOGP_OK) return rc;
@@ -353,7 +358,7 @@ static int upload_params(gogp_handle *h) {
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_BASE = 8 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_BASE = 8 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static hipEvent_t ev(gogp_handle *h, size_t i) {
@@ -435,9 +440,12 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipStreamWaitEvent(sp, ev(h, EV_TRTRI), 0);
     h->trtri_pending = false;
   }
+  // ... and possibly the early LAUUM part (writes bufA, reads Y)
+  if (h->lauum_ksplit > 0) (void)hipStreamWaitEvent(s, ev(h, EV_LAUUM1), 0);
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
   h->trtri_done = false;
+  h->lauum_ksplit = 0;
   h->notpd = -1;
   int rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
@@ -511,6 +519,18 @@ static int factorize(gogp_handle *h, bool eager) {
     if (eager) {
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
       trtri_superstep(h, P0, nsub, st, s2);
+      // Split LAUUM: once the column panels [0, CE) of Y are final, the part of
+      // K^-1 = Y Y^T that only sums k < CE can run (low-priority stream) while both
+      // sweeps wind down.  It writes lower tiles with rows < CE of bufA, which the
+      // Cholesky sweep has finished with (its work area is now rows/cols >= CE).
+      if (h->lauum_split_pct > 0 && h->lauum_ksplit == 0 && CE < npad &&
+          CE * 100 >= npad * (int64_t)h->lauum_split_pct) {
+        (void)hipStreamWaitEvent(h->sl, ev(h, EV_BASE + 4 * P0 + 2), 0);
+        launch_dgemm_nt(h->sl, GEMM_LAUUM, (int)(CE / TILE), (int)(CE / TILE), CE, 1.0, h->bufY, ld,
+                        h->bufY, ld, 0.0, h->bufA, ld, pf);
+        (void)hipEventRecord(ev(h, EV_LAUUM1), h->sl);
+        h->lauum_ksplit = CE;
+      }
     }
   }
   if (eager) {
@@ -545,6 +565,8 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s2);
+    (void)hipStreamSynchronize(h->sl);
+    h->lauum_ksplit = 0;
     h->alpha_pending = false;
     h->trtri_done = h->trtri_pending = false;
     h->notpd = (int64_t)info - 1;
@@ -685,9 +707,11 @@ static int compute_kinv(gogp_handle *h) {
     (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
   }
   h->trtri_pending = false;
-  // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
+  // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over
+  // it.  With a split LAUUM the k < lauum_ksplit part was summed during the sweep.
+  if (h->lauum_ksplit > 0) (void)hipStreamWaitEvent(s, ev(h, EV_LAUUM1), 0);
   launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, h->bufY, ld, h->bufY, ld, 0.0,
-                  h->bufA, ld, pf);
+                  h->bufA, ld, pf, h->lauum_ksplit, npad);
   h->have_kinv = true;
   return GOGP_OK;
 }
@@ -865,7 +889,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   h->observed = false;
   h->grad_valid = false;
   h->have_kinv = false;
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_done = h->trtri_pending = false;
   if (h->n == 0) return GOGP_OK;
   rc = upload_params(h);
@@ -913,7 +937,7 @@ extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_
                                  double *gemm_flops, double *gemm_busy_ms) {
   if (!h) return GOGP_EARG;
   HIPCHK(h, hipSetDevice(h->device));
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st}) HIPCHK(h, hipStreamSynchronize(q));
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   double ms = 0.0, busy = 0.0;
   // launches run concurrently on up to four streams: besides the sum of the
   // per-launch durations report the length of the UNION of the launch intervals
@@ -957,6 +981,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   }
   if (strcmp(name, "eager") == 0) {
     h->eager = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "lauum_split") == 0) {
+    if (value < 0 || value > 95) return fail(h, GOGP_EARG, "lauum_split must be 0..95 (percent)");
+    h->lauum_split_pct = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "superpanel") == 0) {

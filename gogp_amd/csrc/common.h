@@ -49,11 +49,12 @@ enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2 };
 
 // C(mt*128 x nt*128) = beta*C + alpha * A * B^T, row-major, K multiple of 16.
 // GEMM_LOWER: square tile grid mt x mt, only tiles ti >= tj.
-// GEMM_LAUUM: lower tiles; tile (ti,tj) sums k over [ti*128, K).
+// GEMM_LAUUM: lower tiles; tile (ti,tj) sums k over [max(ti*128, kskip), kend) (kend = 0: K)
+// and accumulates into C where its range was cut by kskip (split LAUUM).
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
                      double alpha, const double *A, int64_t lda, const double *B,
                      int64_t ldb, double beta, double *C, int64_t ldc,
-                     GemmProfile *prof);
+                     GemmProfile *prof, int64_t kskip = 0, int64_t kend = 0);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);

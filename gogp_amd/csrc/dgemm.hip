@@ -20,6 +20,8 @@
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so
 // that the MFMA fragment reads (16 rows x 2 k per 32-lane group, ds_read_b64)
 // hit 32 distinct 8-B bank pairs: conflict-free.
+#include <algorithm>
+
 #include "common.h"
 
 namespace gogp {
@@ -35,6 +37,9 @@ struct GemmArgs {
   int mt, nt;
   int nkt;  // K / 16
   double alpha, beta;
+  // GEMM_LAUUM only: the K range of tile (ti,tj) is [max(ti*BT, kskip), kend); tiles
+  // whose range starts below kskip accumulate (beta = 1), the others overwrite
+  int kskip, kend;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -74,8 +79,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
   }
-  const int kbeg = (MODE == GEMM_LAUUM) ? ti * BT : 0;
-  const int nkt = g.nkt - kbeg / GEMM_BK;
+  int kbeg = 0, nkt = g.nkt;
+  double beta = g.beta;
+  if (MODE == GEMM_LAUUM) {
+    kbeg = ti * BT;
+    if (kbeg < g.kskip) {  // second pass of a split LAUUM: [0, kskip) was summed before
+      kbeg = g.kskip;
+      beta = 1.0;
+    }
+    nkt = (g.kend - kbeg) / GEMM_BK;
+    if (nkt <= 0) return;  // whole-workgroup exit (tile-uniform)
+  }
 
   const double *Ag = g.A + (long)ti * BT * g.lda + kbeg;
   const double *Bg = g.B + (long)tj * BT * g.ldb + kbeg;
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
   double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
   const int ccol = lane & 15;
   const int crow = lane >> 4;
-  const double alpha = g.alpha, beta = g.beta;
+  const double alpha = g.alpha;
 
   f64x2 ra[NQ], rb[NQ];
   // prologue loads of k-tile 0 go out first, the C tile right behind them: the
@@ -192,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
 
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
                      const double *A, int64_t lda, const double *B, int64_t ldb,
-                     double beta, double *C, int64_t ldc, GemmProfile *prof) {
+                     double beta, double *C, int64_t ldc, GemmProfile *prof, int64_t kskip,
+                     int64_t kend) {
   if (mt <= 0 || nt <= 0 || K <= 0) return;
   GemmArgs g;
   g.A = A;
@@ -206,6 +221,9 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.nkt = (int)(K / GEMM_BK);
   g.alpha = alpha;
   g.beta = beta;
+  if (kend <= 0 || kend > K) kend = K;
+  g.kskip = (int)kskip;
+  g.kend = (int)kend;
   int ntiles;
   double flops;
   if (mode == GEMM_RECT) {
@@ -217,8 +235,10 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
       flops = 2.0 * (double)ntiles * TILE * TILE * (double)K;
     } else {
       flops = 0;
-      for (int i = 0; i < mt; ++i)
-        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - (int64_t)i * TILE);
+      for (int i = 0; i < mt; ++i) {
+        const int64_t kb = std::max<int64_t>((int64_t)i * TILE, kskip);
+        if (kend > kb) flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(kend - kb);
+      }
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -1,0 +1,155 @@
+"""Hyperparameter optimisation loop over Observe/Gradient ("next" row 1 of
+SURVEY.md section 8f).
+
+The reference drives ``m.Observe`` / ``model.Gradient(m)`` through
+``infer.FuncGrad`` and gonum's ``optimize.Minimize`` with the default method for
+problems with a gradient (L-BFGS), ``MajorIterations = 1000`` and
+``GradientThreshold = 1e-6`` (tutorial/tutorial.go:128-155).  gonum's source is
+not available here, so iterate-by-iterate parity is unpinned; this module is a
+plain L-BFGS (two-loop recursion, backtracking/Armijo + curvature-safeguarded
+line search) on the NEGATIVE log marginal likelihood with the same stopping
+rule, so that final LML / theta can be compared from identical starts.
+
+Every function value needs one Observe; the gradient of the accepted point comes
+from the same evaluation (the fused sweep prepares it during Observe), so an
+iteration with an accepted first trial costs exactly one Observe + Gradient.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class Result:
+    x: np.ndarray
+    lml: float
+    grad: np.ndarray
+    iterations: int
+    evaluations: int
+    converged: bool
+    history: List[float] = field(default_factory=list)
+
+
+def func_grad(m):
+    """infer.FuncGrad(m) (tutorial/tutorial.go:131): closures returning the
+    NEGATED log-likelihood and gradient of an elemental model."""
+
+    def f(x):
+        return -m.Observe(x)
+
+    def g(x):
+        m.Observe(x)
+        return -np.asarray(m.Gradient())
+
+    return f, g
+
+
+def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
+          history_size: int = 10, max_step_log: float = 2.0,
+          callback: Optional[Callable[[int, np.ndarray, float], None]] = None) -> Result:
+    """Maximise m.Observe(x) (LML) over x = log theta with L-BFGS.
+
+    ``m`` is a gogp_amd.gp.GP, a gogp_amd.gp.Model, or anything with
+    Observe(x)/Gradient().  Stops when ||grad||_inf <= gradient_threshold
+    (gonum's GradientThreshold) or after major_iterations."""
+    x = np.array(x0, dtype=float)
+    evals = 0
+
+    def value_and_grad(xx):
+        nonlocal evals
+        evals += 1
+        try:
+            v = m.Observe(xx)
+        except Exception:  # not positive definite etc.: treat as +inf objective
+            return np.inf, None
+        if not np.isfinite(v):
+            return np.inf, None
+        return -v, None
+
+    f, _ = value_and_grad(x)
+    if not np.isfinite(f):
+        raise ValueError("initial point is not feasible")
+    g = -np.asarray(m.Gradient(), dtype=float)
+    S: List[np.ndarray] = []
+    Yv: List[np.ndarray] = []
+    hist = [-f]
+    converged = False
+    it = 0
+    for it in range(1, major_iterations + 1):
+        if np.abs(g).max() <= gradient_threshold:
+            converged = True
+            break
+        # two-loop recursion
+        q = g.copy()
+        al = []
+        for s, yv in zip(reversed(S), reversed(Yv)):
+            rho = 1.0 / float(yv @ s)
+            a = rho * float(s @ q)
+            al.append((a, rho, s, yv))
+            q -= a * yv
+        if S:
+            gamma = float(S[-1] @ Yv[-1]) / float(Yv[-1] @ Yv[-1])
+            q *= gamma
+        for a, rho, s, yv in reversed(al):
+            b = rho * float(yv @ q)
+            q += (a - b) * s
+        d = -q
+        if float(d @ g) >= 0:  # not a descent direction: reset
+            d = -g
+            S.clear()
+            Yv.clear()
+        # cap the step in log-theta space (keeps K positive definite in practice)
+        step = 1.0
+        dmax = np.abs(d).max()
+        if dmax * step > max_step_log:
+            step = max_step_log / dmax
+        if not S:
+            step = min(step, 1.0 / max(1.0, np.abs(g).max()))
+        slope = float(d @ g)
+        accepted = False
+        for _ in range(30):
+            xn = x + step * d
+            fn, _ = value_and_grad(xn)
+            if np.isfinite(fn) and fn <= f + 1e-4 * step * slope:
+                accepted = True
+                break
+            step *= 0.5
+        if not accepted:
+            break
+        gn = -np.asarray(m.Gradient(), dtype=float)
+        s_vec, y_vec = xn - x, gn - g
+        if float(s_vec @ y_vec) > 1e-12 * float(np.linalg.norm(s_vec) * np.linalg.norm(y_vec)):
+            S.append(s_vec)
+            Yv.append(y_vec)
+            if len(S) > history_size:
+                S.pop(0)
+                Yv.pop(0)
+        x, f, g = xn, fn, gn
+        hist.append(-f)
+        if callback:
+            callback(it, x, -f)
+    return Result(x=x, lml=-f, grad=-g, iterations=it, evaluations=evals, converged=converged,
+                  history=hist)
+
+
+class NormalLogPriors:
+    """Independent Normal log-priors on the (log-scale) parameters, the shape of
+    tutorial/hyperpriors/model/model.go: Observe sums log-densities, Gradient
+    returns their derivatives (an elemental model for gp.Model.Priors)."""
+
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean, dtype=float)
+        self.std = np.asarray(std, dtype=float)
+        self._x = None
+
+    def Observe(self, x) -> float:
+        x = np.asarray(x, dtype=float)[:len(self.mean)]
+        self._x = x
+        z = (x - self.mean) / self.std
+        return float((-0.5 * z * z - np.log(self.std) - 0.5 * np.log(2 * np.pi)).sum())
+
+    def Gradient(self) -> np.ndarray:
+        return -(self._x - self.mean) / (self.std ** 2)
