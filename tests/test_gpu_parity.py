@@ -378,3 +378,130 @@ def test_config3_full_size_properties(gpmod):
     got = float((sigma ** 2).sum())
     assert abs(got - want) <= 1e-6 * abs(want), (got, want)
     assert np.isfinite(lml)
+
+
+def test_handle_reuse_across_sizes_and_call_orders(gpmod):
+    """One GP value reused with growing and shrinking data, every call order the API
+    allows (Observe -> Gradient twice, Observe -> Observe, Observe -> Absorb -> Produce,
+    Produce right after an eager Observe while its gradient preparation is in flight)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(41)
+    D = 2
+    simil, noise = kernel.Scaled(kernel.Matern32), kernel.UniformNoise
+    g = gpmod.GP(D, simil, noise)
+    o = FastOracle(D, simil, noise)
+    x = np.log([1.2, 0.4, 0.3])
+    for n in (300, 900, 100, 513):
+        X, y = _data(rng, n, D)
+        g.X, g.Y = X, y
+        o.set_data(X, y)
+        lml_o = o.Observe(x)
+        grad_o = o.Gradient()
+        Z = rng.uniform(0, 1, (11, D))
+        mu_o, sig_o = o.Produce(Z)
+        # Observe -> Produce immediately (triangular inverse still running) -> Gradient x2
+        assert abs(g.Observe(x) - lml_o) <= 1e-8 * abs(lml_o)
+        mu, sig = g.Produce(Z)
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(sig, sig_o, rtol=1e-6, atol=1e-8)
+        g1, g2 = g.Gradient(), g.Gradient()
+        np.testing.assert_array_equal(g1, g2)
+        assert np.abs(g1 - grad_o).max() <= 1e-6 * max(1.0, np.abs(grad_o).max())
+        # Observe twice in a row (the first one's gradient preparation is abandoned)
+        g.Observe(x + 0.05)
+        assert abs(g.Observe(x) - lml_o) <= 1e-8 * abs(lml_o)
+        # Absorb after Observe: no gradient any more, Produce still right
+        g.ThetaSimil, g.ThetaNoise = list(np.exp(x[:2])), list(np.exp(x[2:]))
+        g.Absorb(X, y)
+        assert abs(g.LML() - lml_o) <= 1e-8 * abs(lml_o)
+        with pytest.raises(gpmod.GogpError):
+            g.Gradient()
+        mu, sig = g.Produce(Z)
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+
+
+def test_lazy_and_eager_paths_agree_bitwise_on_lml(gpmod):
+    """eager=0 (triangular inverse on demand, backward substitution for alpha) and the
+    fused sweep give the same LML bit for bit and the same gradient to rounding."""
+    rng = np.random.default_rng(43)
+    n, D = 1100, 3
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    x = np.log([0.9, 0.5, 0.15])
+    a = gpmod.GP(D, simil, noise, X=X, Y=y)
+    b = gpmod.GP(D, simil, noise, X=X, Y=y)
+    b.set_option("eager", 0)
+    c = gpmod.GP(D, simil, noise, X=X, Y=y)
+    c.set_option("lookahead", 0)
+    d = gpmod.GP(D, simil, noise, X=X, Y=y)
+    d.set_option("superpanel", 1)
+    la, lb, lc, ld_ = a.Observe(x), b.Observe(x), c.Observe(x), d.Observe(x)
+    assert la == lb == lc
+    assert abs(la - ld_) <= 1e-12 * abs(la)
+    ga = a.Gradient()
+    for other in (b, c, d):
+        np.testing.assert_allclose(other.Gradient(), ga, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b.Alpha, a.Alpha, rtol=1e-8, atol=1e-10)
+    # run to run: bitwise reproducible (fixed-order reductions, no float atomics)
+    assert a.Observe(x) == la
+    np.testing.assert_array_equal(a.Gradient(), ga)
+
+
+def test_two_handles_interleaved(gpmod):
+    """Different GP values are independent (each owns its streams and buffers)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(47)
+    cases = []
+    for D, simil in ((1, kernel.Scaled(kernel.Normal)), (4, kernel.Scaled(kernel.Matern52))):
+        X, y = _data(rng, 400, D)
+        g = gpmod.GP(D, simil, kernel.UniformNoise, X=X, Y=y)
+        o = FastOracle(D, simil, kernel.UniformNoise)
+        o.set_data(X, y)
+        cases.append((g, o))
+    x = np.log([1.0, 0.5, 0.2])
+    lmls = [g.Observe(x) for g, _ in cases]  # both evaluations in flight before any gradient
+    for (g, o), lml in zip(cases, lmls):
+        assert abs(lml - o.Observe(x)) <= 1e-8 * abs(lml)
+        go = o.Gradient()
+        assert np.abs(g.Gradient() - go).max() <= 1e-6 * max(1.0, np.abs(go).max())
+
+
+def test_ard_high_dimension(gpmod):
+    """ARD-RBF at D=32 (the kernel of BASELINE config 5): P = 34 parameters."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(53)
+    n, D = 700, 32
+    X, y = _data(rng, n, D)
+    simil = kernel.Scaled(kernel.ARD(kernel.Normal, D))
+    ls = math.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D))
+    x = np.log(np.concatenate([[1.0], ls, [0.1]]))
+    g = gpmod.GP(D, simil, kernel.UniformNoise, X=X, Y=y)
+    o = FastOracle(D, simil, kernel.UniformNoise)
+    o.set_data(X, y)
+    lml, lml_o = g.Observe(x), o.Observe(x)
+    assert abs(lml - lml_o) <= 1e-8 * abs(lml_o)
+    gr, gr_o = g.Gradient(), o.Gradient()
+    assert gr.shape == (34,)
+    assert np.abs(gr - gr_o).max() <= 1e-6 * max(1.0, np.abs(gr_o).max())
+
+
+def test_near_duplicate_inputs_with_default_noise(gpmod):
+    """Nearly coincident inputs: K is close to singular and only the default
+    ConstantNoise(1e-5) (gp/gp.go:43-48) keeps it positive definite."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(59)
+    base = rng.uniform(0, 1, (30, 1))
+    X = np.concatenate([base, base + 1e-7])
+    y = np.sin(6 * X[:, 0])
+    g = gpmod.GP(1, kernel.Scaled(kernel.Normal), None, X=X, Y=y)
+    o = Oracle(1, kernel.Scaled(kernel.Normal), None)
+    o.set_data(X, y)
+    x = np.log([1.0, 0.3])
+    try:
+        lml_o = o.Observe(x)
+    except Exception:
+        with pytest.raises(gpmod.FactorizeError):
+            g.Observe(x)
+        return
+    # cond(K) ~ 1e10: agree to cond * eps
+    assert abs(g.Observe(x) - lml_o) <= 1e-4 * abs(lml_o)
