@@ -18,14 +18,13 @@
 // (upper zero-filled), which turns every panel solve of the callers into a
 // single K=256 GEMM  (panel) * Dinv^T.
 //
-// chol(128) is blocked by 16: per block step  potrf16+inv16 (wave 0) ->
-// TRSM as MFMA with the 16x16 inverse -> SYRK as MFMA; the 128x128 inverse is
-// assembled from the eight 16x16 inverses by recursive doubling
-// (X21 = -X22 L21 X11 at sizes 16, 32, 64), again MFMA.
+// chol(128) is blocked by 16 with in-kernel look-ahead (see potrf128_lds); the
+// 128x128 inverse is assembled from the eight 16x16 inverses by recursive doubling
+// (X21 = -X22 L21 X11 at sizes 16, 32, 64) on MFMA.
 //
 // LDS: S[128][130] doubles (padding 2 => the MFMA fragment reads of 16 rows x
 // 2 k hit 64 distinct banks), G = 2304 doubles shared by the eight 16x16
-// inverses (during chol) and the staging chunks of the 128^3 products.
+// inverses.
 #include "common.h"
 
 namespace gogp {
@@ -35,8 +34,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int SLD = 130;   // leading dimension of S
-constexpr int GNT = 18;    // G viewed as [128][18]  (B staged as rows j, 16 k each)
-constexpr int GNN = 144;   // G viewed as [16][144]  (B staged as 16 k-rows of 128 j)
 constexpr int XLD = 18;    // a 16x16 inverse block: [16][18]
 constexpr int GSIZE = 2304;
 constexpr int NT = 512;  // threads per workgroup
@@ -53,101 +50,128 @@ __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// 16x16 base case by ONE wave: lanes 0..15 own row r of the block (lanes 16..63
-// mirror them).  Cholesky right-looking with v_readlane broadcasts, then the
-// inverse of the factor by forward substitution (lane c owns column c).
-// With DO_POTRF=false the block already holds the factor and only the inverse
-// is formed.  Writes the factor (upper zeroed) back to S and the inverse to Xb.
-template <bool DO_POTRF>
-__device__ __forceinline__ void base16(double *S, int kb, double *Xb, volatile double *rinv,
-                                       int lane, long grow0, long nvalid, long long *info) {
+// 16x16 Cholesky by ONE wave: lanes 0..15 own row r of the block (lanes 16..63
+// mirror them), right-looking with v_readlane broadcasts; 1/sqrt by v_rsq_f64 +
+// two Newton steps.  Writes the factor (upper zeroed) back to S and 1/L_jj to
+// rinv[0..15] (LDS).
+__device__ __forceinline__ void potrf16(double *S, int kb, volatile double *rinv, int lane,
+                                        long grow0, long nvalid, long long *info) {
   const int r = lane & 15;
   double a[16];
   double *src = S + (kb * 16 + r) * SLD + kb * 16;
 #pragma unroll
   for (int c = 0; c < 16; ++c) a[c] = src[c];
-  // rinv[j] = 1 / L_jj (wave-uniform) lives in LDS to keep the register count
-  // under the 128-VGPR budget of a 1024-thread workgroup (same-wave LDS
-  // accesses are ordered)
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     double d = readlane_d(a[j], j);
-    if (DO_POTRF) {
-      if (!(d > 0.0)) {
-        if (lane == 0 && grow0 + j < nvalid && *info == 0) *info = (long long)(grow0 + j + 1);
-        d = 1.0;
-      }
-      // 1/sqrt(d): hardware estimate + two Newton steps (full double accuracy
-      // without the long sqrt + divide sequences on the serial path)
-      double rs = __builtin_amdgcn_rsq(d);
-      rs = fma(rs * 0.5, fma(-d * rs, rs, 1.0), rs);
-      rs = fma(rs * 0.5, fma(-d * rs, rs, 1.0), rs);
-      if (lane == 0) rinv[j] = rs;
-      const double lrj = a[j] * rs;  // lane j: d/sqrt(d) = sqrt(d)
-      a[j] = lrj;
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) a[c] -= lrj * readlane_d(lrj, c);
-    } else {
-      double ri = __builtin_amdgcn_rcp(d);
-      ri = fma(ri, fma(-d, ri, 1.0), ri);
-      ri = fma(ri, fma(-d, ri, 1.0), ri);
-      if (lane == 0) rinv[j] = ri;
+    if (!(d > 0.0)) {
+      if (lane == 0 && grow0 + j < nvalid && *info == 0) *info = (long long)(grow0 + j + 1);
+      d = 1.0;
     }
+    double rs = __builtin_amdgcn_rsq(d);
+#ifndef GOGP_RSQ_NEWTON
+#define GOGP_RSQ_NEWTON 2
+#endif
+#pragma unroll
+    for (int it = 0; it < GOGP_RSQ_NEWTON; ++it) rs = fma(rs * 0.5, fma(-d * rs, rs, 1.0), rs);
+    if (lane == 0) rinv[j] = rs;
+    const double lrj = a[j] * rs;  // lane j: d/sqrt(d) = sqrt(d)
+    a[j] = lrj;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] -= lrj * readlane_d(lrj, c);
   }
-  // inverse: x[rr] = X[rr][c] for this lane's column c = r
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) src[c] = (c <= r) ? a[c] : 0.0;
+  }
+}
+
+// Inverse of the 16x16 lower-triangular diagonal block kb of S by ONE wave (lane c
+// owns column c, forward substitution with v_readlane broadcasts of the rows).
+// HAVE_RINV: 1/L_jj is already in rinv[]; otherwise it is formed here.
+template <bool HAVE_RINV>
+__device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, volatile double *rinv,
+                                      int lane) {
+  const int r = lane & 15;
+  double a[16];
+  const double *src = S + (kb * 16 + r) * SLD + kb * 16;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = src[c];
   double x[16];
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     double s = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < rr; ++q) s -= readlane_d(a[q], rr) * x[q];
-    x[rr] = (rr >= r) ? s * rinv[rr] : 0.0;
+    double ri;
+    if (HAVE_RINV) {
+      ri = rinv[rr];
+    } else {
+      const double d = readlane_d(a[rr], rr);
+      ri = __builtin_amdgcn_rcp(d);
+      ri = fma(ri, fma(-d, ri, 1.0), ri);
+      ri = fma(ri, fma(-d, ri, 1.0), ri);
+    }
+    x[rr] = (rr >= r) ? s * ri : 0.0;
   }
   if (lane < 16) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) src[c] = (c <= r) ? a[c] : 0.0;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) Xb[rr * XLD + r] = x[rr];
   }
 }
 
-// In-LDS blocked Cholesky of the 128x128 matrix in S (lower triangle valid,
-// upper zero).  On exit S = L (upper zero), XD[kb] = inverse of L's kb-th 16x16
-// diagonal block.
+// In-LDS blocked Cholesky of the 128x128 matrix in S (lower triangle valid, upper
+// zero), block size 16, with in-kernel look-ahead:
+//   panel solve  : every row below the diagonal block is solved by ONE lane
+//                  (forward substitution against the 16x16 factor, broadcast LDS reads);
+//   trailing     : MFMA rank-16 updates; wave 0 updates the next diagonal tile first
+//                  and factors it while waves 1..7 update the other tiles.
+// On exit S = L (upper zero) and XD[kb] = inverse of L's kb-th diagonal block (the
+// eight inverses are formed at the end by eight waves in parallel).
 __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long grow0,
                              long nvalid, long long *info, unsigned long long *st = nullptr) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
+  if (w == 0) potrf16(S, 0, rinv, lane, grow0, nvalid, info);
+  __syncthreads();
   for (int kb = 0; kb < 8; ++kb) {
-    if (w == 0)
-      base16<true>(S, kb, XD + kb * 16 * XLD, rinv, lane, grow0 + kb * 16, nvalid, info);
-    if (st && tid == 0 && kb < 2) st[kb * 3 + 0] = __builtin_amdgcn_s_memtime();
-    __syncthreads();
-    // panel: L[i,kb] = A[i,kb] * X^T  (X = inverse of the diagonal block)
+    // ---- panel solve: rows (kb+1)*16 .. 127, one lane per row -----------------------
     {
-      const int i = kb + 1 + w;
-      if (i < 8) {
-        const double *Xb = XD + kb * 16 * XLD;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        double a4[4], b4[4];
+      const int row = (kb + 1) * 16 + tid;
+      if (row < 128) {
+        double *ap = S + row * SLD + kb * 16;
+        const double *Lb = S + (kb * 16) * SLD + kb * 16;
+        const double *ri = rinv + kb * 16;
+        double x[16];
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          a4[k4] = S[(i * 16 + fr) * SLD + kb * 16 + k4 * 4 + fk];
-          b4[k4] = Xb[fr * XLD + k4 * 4 + fk];
+        for (int c = 0; c < 16; ++c) x[c] = ap[c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          // row c of the 16x16 factor: broadcast LDS reads issued together, consumed at
+          // once; the fence keeps hipcc from hoisting all 120 reads (register spills)
+          double lr[16];
+#pragma unroll
+          for (int q = 0; q < c; ++q) lr[q] = Lb[c * SLD + q];
+          double t = x[c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) t -= x[q] * lr[q];
+          x[c] = t * ri[c];
+          asm volatile("" ::: "memory");
         }
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) acc = mfma(a4[k4], b4[k4], acc);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) S[(i * 16 + fk + 4 * v) * SLD + kb * 16 + fr] = acc[v];
+        for (int c = 0; c < 16; ++c) ap[c] = x[c];
       }
     }
     if (st && tid == 0 && kb < 2) st[kb * 3 + 1] = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    // trailing update: A[i,c] -= L[i,kb] L[c,kb]^T for kb < c <= i
+    if (kb == 7) break;
+    // ---- trailing update A[i,c] -= L[i,kb] L[c,kb]^T for kb < c <= i ---------------------
     {
       const int m = 7 - kb;
       const int nt3 = m * (m + 1) / 2;
-      for (int t = w; t < nt3; t += NW) {
+      // wave 0: tile 0 = (kb+1, kb+1), then the next 16x16 factorisation;
+      // waves 1..7: tiles 1 .. nt3-1
+      for (int t = (w == 0 ? 0 : w); t < (w == 0 ? 1 : nt3); t += 7) {
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
         const int cc = t - ii * (ii + 1) / 2;
@@ -162,10 +186,16 @@ __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long 
 #pragma unroll
         for (int v = 0; v < 4; ++v) S[(i * 16 + fk + 4 * v) * SLD + c * 16 + fr] -= acc[v];
       }
+      if (w == 0) {
+        potrf16(S, kb + 1, rinv + (kb + 1) * 16, lane, grow0 + (kb + 1) * 16, nvalid, info);
+        if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
+      }
     }
-    if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
     __syncthreads();
   }
+  // ---- the eight 16x16 inverses, one wave each ----------------------------------------
+  inv16<true>(S, w, XD + w * 16 * XLD, rinv + w * 16, lane);
+  __syncthreads();
 }
 
 // S holds a lower-triangular L (128x128) whose eight 16x16 diagonal-block
@@ -245,13 +275,14 @@ __device__ void invert128_lds(double *S, const double *XD, int tid) {
 }
 
 // C (128x128; wave (wr,wc) of a 4x2 arrangement owns rows wr*32.., cols wc*64..:
-// 2x4 MFMA tiles) = A * B with A = S (LDS, row-major [i][k]) and B read from
-// global memory, staged through G in chunks of 16 k:
+// 2x4 MFMA tiles) = A * B with A = S (LDS, row-major [i][k]) and the B fragments
+// loaded straight from global memory (L2-resident, written earlier by this
+// workgroup) one 16-k chunk ahead: no staging buffer and no barrier inside.
 //   B_NT: B[k][j] = Bg[j*ldb + k]   (rows of Bg are the columns of B)
 //   else: B[k][j] = Bg[k*ldb + j]
 template <bool B_NT>
 __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, const double *Bg, long ldb,
-                           double *G, int tid) {
+                           int tid) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int wr = w >> 1, wc = w & 1;
@@ -259,48 +290,54 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, const double *Bg, 
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) c[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  // staging map: two 16-B pieces (4 consecutive doubles) per thread per chunk
-  const double *src;
-  int goff;
-  long kstep;
-  if (B_NT) {
-    const int j = tid >> 2, c4 = (tid & 3) * 4;
-    src = Bg + (long)j * ldb + c4;
-    goff = j * GNT + c4;
-    kstep = 16;
-  } else {
-    const int kk = tid >> 5, j4 = (tid & 31) * 4;
-    src = Bg + (long)kk * ldb + j4;
-    goff = kk * GNN + j4;
-    kstep = 16 * ldb;
+  // The k index inside an MFMA step is arbitrary as long as A and B agree.
+  //   NN: lane group fk supplies k = 4*s + fk in step s (rows of Bg are k: the 16
+  //       lanes of a group read 128 contiguous bytes);
+  //   NT: lane group fk supplies k = 4*fk + s in step s, so that a lane's four k of
+  //       a 16-k chunk are 32 contiguous bytes of ITS row of Bg (two 16-B loads per
+  //       chunk, the four groups cover the row's whole 128-B line).
+  const double *pn[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    pn[n] = B_NT ? Bg + (long)(wc * 64 + n * 16 + fr) * ldb + 4 * fk
+                 : Bg + (long)fk * ldb + wc * 64 + n * 16 + fr;
+  const double *ap = S + (wr * 32 + fr) * SLD + (B_NT ? 4 * fk : fk);
+  constexpr int ASTEP = B_NT ? 1 : 4;  // A column advance per k4 step inside a chunk
+  double bA[4][4], bB[4][4];
+#define GOGP_LOADB(dst)                                                              \
+  if (B_NT) {                                                                        \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                  \
+      const double2 v0 = *reinterpret_cast<const double2 *>(pn[n]);                  \
+      const double2 v1 = *reinterpret_cast<const double2 *>(pn[n] + 2);              \
+      dst[0][n] = v0.x; dst[1][n] = v0.y; dst[2][n] = v1.x; dst[3][n] = v1.y;        \
+      pn[n] += 16;                                                                   \
+    }                                                                                \
+  } else {                                                                           \
+    _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                               \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) dst[k4][n] = pn[n][0];           \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) pn[n] += 4 * ldb;                \
+    }                                                                                \
   }
-  double2 n0 = *reinterpret_cast<const double2 *>(src);
-  double2 n1 = *reinterpret_cast<const double2 *>(src + 2);
-  for (int kc = 0; kc < 8; ++kc) {
-    __syncthreads();  // readers of the previous chunk are done
-    *reinterpret_cast<double2 *>(G + goff) = n0;
-    *reinterpret_cast<double2 *>(G + goff + 2) = n1;
-    if (kc + 1 < 8) {
-      n0 = *reinterpret_cast<const double2 *>(src + (long)(kc + 1) * kstep);
-      n1 = *reinterpret_cast<const double2 *>(src + (long)(kc + 1) * kstep + 2);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      double a[2], b[4];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = S[(wr * 32 + m * 16 + fr) * SLD + kc * 16 + k4 * 4 + fk];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        b[n] = B_NT ? G[(wc * 64 + n * 16 + fr) * GNT + k4 * 4 + fk]
-                    : G[(k4 * 4 + fk) * GNN + wc * 64 + n * 16 + fr];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) c[m][n] = mfma(a[m], b[n], c[m][n]);
-    }
+#define GOGP_CHUNK(cur, kc)                                                          \
+  _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                                 \
+    const double a0 = ap[(kc) * 16 + k4 * ASTEP];                                    \
+    const double a1 = ap[16 * SLD + (kc) * 16 + k4 * ASTEP];                         \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                  \
+      c[0][n] = mfma(a0, cur[k4][n], c[0][n]);                                       \
+      c[1][n] = mfma(a1, cur[k4][n], c[1][n]);                                       \
+    }                                                                                \
   }
-  __syncthreads();
+  GOGP_LOADB(bA)
+#pragma unroll 1
+  for (int kc = 0; kc < 8; kc += 2) {
+    GOGP_LOADB(bB)  // chunk kc+1 in flight while chunk kc computes
+    GOGP_CHUNK(bA, kc)
+    if (kc + 2 < 8) { GOGP_LOADB(bA) }
+    GOGP_CHUNK(bB, kc + 1)
+  }
+#undef GOGP_CHUNK
+#undef GOGP_LOADB
+  __syncthreads();  // every wave is done reading S
 }
 
 }  // namespace
@@ -339,14 +376,18 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
     GOGP_STAMP(half * 8 + 0);
     // ---- S <- diagonal 128-block (half 0: A00; half 1: A11 - L10 L10^T) ----------
     if (half == 0 || !DO_POTRF) {
-      for (int idx = tid; idx < 128 * 128; idx += NT) {
-        const int i = idx >> 7, cc = idx & 127;
-        S[i * SLD + cc] = (cc <= i) ? A[(off + i) * ld + off + cc] : 0.0;
+      // unconditional 16-B loads, then select: a conditional load compiles into a
+      // serialised branch + load + vmcnt(0) per element
+      for (int idx = tid; idx < 128 * 64; idx += NT) {
+        const int i = idx >> 6, cc = (idx & 63) * 2;
+        const double2 v = *reinterpret_cast<const double2 *>(A + (off + i) * ld + off + cc);
+        S[i * SLD + cc] = (cc <= i) ? v.x : 0.0;
+        S[i * SLD + cc + 1] = (cc + 1 <= i) ? v.y : 0.0;
       }
       __syncthreads();
     } else {
       // S currently holds L10 (row-major): C = L10 * L10^T
-      wg_gemm128<true>(c, S, L10g, ld10, G, tid);
+      wg_gemm128<true>(c, S, L10g, ld10, tid);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -354,7 +395,8 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int i = wr * 32 + m * 16 + fk + 4 * v, cc = wc * 64 + n * 16 + fr;
-            S[i * SLD + cc] = (cc <= i) ? A[(128 + i) * ld + 128 + cc] - c[m][n][v] : 0.0;
+            const double a11 = A[(128 + i) * ld + 128 + cc];  // unconditional load, then select
+            S[i * SLD + cc] = (cc <= i) ? a11 - c[m][n][v] : 0.0;
           }
       __syncthreads();
     }
@@ -370,7 +412,7 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
         if (half == 0) Lout[i * ldl + 128 + cc] = 0.0;  // upper-right block of the factor
       }
     } else {
-      if (w < 8) base16<false>(S, w, G + w * 16 * XLD, rinv_s + w * 16, lane, 0, 0, nullptr);
+      inv16<false>(S, w, G + w * 16 * XLD, rinv_s + w * 16, lane);
     }
     __syncthreads();
     GOGP_STAMP(half * 8 + 3);
@@ -387,7 +429,7 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
     if (half == 0) {
       // ---- L10 = A10 X00^T, computed as C = X00 * A10^T = L10^T ------------------------
       if (DO_POTRF) {
-        wg_gemm128<true>(c, S, A + 128 * ld, ld, G, tid);
+        wg_gemm128<true>(c, S, A + 128 * ld, ld, tid);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -413,7 +455,7 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
   }
   // ---- X10 = -X11 L10 X00 : S = X11 now ------------------------------------------------
   GOGP_STAMP(16);
-  wg_gemm128<false>(c, S, L10g, ld10, G, tid);  // U = X11 * L10
+  wg_gemm128<false>(c, S, L10g, ld10, tid);  // U = X11 * L10
   GOGP_STAMP(17);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -423,7 +465,7 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
       for (int v = 0; v < 4; ++v)
         S[(wr * 32 + m * 16 + fk + 4 * v) * SLD + wc * 64 + n * 16 + fr] = c[m][n][v];
   __syncthreads();
-  wg_gemm128<false>(c, S, Dinv, 256, G, tid);  // U * X00
+  wg_gemm128<false>(c, S, Dinv, 256, tid);  // U * X00
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
