@@ -22,6 +22,10 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _i64 = ctypes.c_int64
 _h = ctypes.c_void_p
 _descp = ctypes.POINTER(CDesc)
+#: callback types of the sharded evaluation (include/gogp_hip.h)
+BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                ctypes.c_int64)
 SYMBOLS = [
     ("gogp_desc_check", ctypes.c_int, [_descp]),
     ("gogp_desc_ntheta_noise", ctypes.c_int, [_descp]),
@@ -41,6 +45,10 @@ SYMBOLS = [
     ("gogp_get_alpha", ctypes.c_int, [_h, _dp]),
     ("gogp_get_factor", ctypes.c_int, [_h, _dp]),
     ("gogp_set_factor", ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
+    ("gogp_dist_staging_bytes", _i64, [_i64]),
+    ("gogp_dist_setup", ctypes.c_int,
+     [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+      ctypes.c_void_p, _i64]),
     ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),

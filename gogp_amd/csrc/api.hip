@@ -58,6 +58,13 @@ struct gogp_handle {
   hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
   hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
                              // skinny updates, substitution steps -- overlaps the big updates
+  // sharded evaluation (gogp_dist_setup); dist_n <= 1: single GPU
+  int dist_rank = 0, dist_n = 1;
+  gogp_bcast_fn dist_bcast = nullptr;
+  gogp_allreduce_fn dist_allreduce = nullptr;
+  void *dist_user = nullptr;
+  double *dist_staging = nullptr;
+  int64_t dist_staging_bytes = 0;
   hipStream_t sl = nullptr;  // early part of K^-1 = Y Y^T (split LAUUM) during the sweep's tail
   int lauum_split_pct = 0;   // K range [0, pct% of N) of LAUUM summed during the sweep; 0 = off
                              // (measured: no gain, the sweep is already throughput-bound)
@@ -595,6 +602,211 @@ static int ensure_alpha(gogp_handle *h) {
   return GOGP_OK;
 }
 
+// ===========================================================================
+// Sharded evaluation: 1-D block-cyclic super-panels over dist_n ranks.
+// Everything runs on the main stream; broadcasts are host-synchronous (the
+// callback returns when the data have arrived).
+// ===========================================================================
+static int dist_owner(const gogp_handle *h, int P0) { return (P0 / h->superpanel) % h->dist_n; }
+
+extern "C" int64_t gogp_dist_staging_bytes(int64_t n) {
+  const int64_t npad = n <= 0 ? PANEL : ((n + PANEL - 1) / PANEL) * PANEL;
+  // a packed panel: up to npad rows x (4 * 256) columns + the diagonal inverses
+  return (npad * 4 * PANEL + 4 * (int64_t)PANEL * PANEL) * (int64_t)sizeof(double);
+}
+
+static int dist_bcast(gogp_handle *h, int64_t bytes, int root) {
+  if (bytes > h->dist_staging_bytes) return fail(h, GOGP_EARG, "dist: staging buffer too small");
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  if (h->dist_bcast(h->dist_user, h->dist_staging, bytes, root) != 0)
+    return fail(h, GOGP_EHIP, "dist: broadcast callback failed");
+  return GOGP_OK;
+}
+
+static int factorize_dist(gogp_handle *h) {
+  const int64_t npad = h->npad, ld = npad;
+  hipStream_t s = h->s;
+  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_pending = false;
+  h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
+  h->alpha_pending = false;
+  h->trtri_done = false;
+  h->lauum_ksplit = 0;
+  h->notpd = -1;
+  int rc = upload_params(h);
+  if (rc != GOGP_OK) return rc;
+  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
+  // every rank builds the whole lower triangle (0.5 ms at N = 16384); it only ever
+  // reads the block columns it owns
+  launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
+  double *A = h->bufA, *L = h->bufL;
+  GemmProfile *pf = &h->prof;
+  const int npanel = (int)(npad / PANEL);
+  const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
+  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int P0 = 0; P0 < npanel; P0 += SW) {
+    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
+    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
+    const int owner = dist_owner(h, P0);
+    double *Dp0 = h->Dinv + (size_t)P0 * PANEL * PANEL;
+    const size_t dbytes = (size_t)nsub * PANEL * PANEL * sizeof(double);
+    const int64_t prow = npad - C0;  // packed panel rows C0 .. npad
+    const size_t pbytes = (size_t)prow * Kw * sizeof(double);
+    if (owner == me) {
+      for (int q = 0; q < nsub; ++q) {
+        const int p = P0 + q;
+        const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
+        double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+        launch_diag256(s, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+        const int mt2 = (int)((npad - c2) / TILE);
+        if (mt2 > 0)
+          launch_dgemm_nt(s, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
+                          L + c2 * ld + c0, ld, pf);
+        for (int64_t cr = c2; cr < CE; cr += PANEL)
+          launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0,
+                          L + cr * ld + c0, ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      }
+      // pack [diagonal inverses | L[C0:npad, C0:CE]] into the staging buffer
+      HIPCHK(h, hipMemcpyAsync(h->dist_staging, Dp0, dbytes, hipMemcpyDeviceToDevice, s));
+      HIPCHK(h, hipMemcpy2DAsync((char *)h->dist_staging + dbytes, Kw * sizeof(double),
+                                 L + C0 * ld + C0, ld * sizeof(double), Kw * sizeof(double), prow,
+                                 hipMemcpyDeviceToDevice, s));
+    }
+    rc = dist_bcast(h, (int64_t)(dbytes + pbytes), owner);
+    if (rc != GOGP_OK) return rc;
+    if (owner != me) {
+      HIPCHK(h, hipMemcpyAsync(Dp0, h->dist_staging, dbytes, hipMemcpyDeviceToDevice, s));
+      HIPCHK(h, hipMemcpy2DAsync(L + C0 * ld + C0, ld * sizeof(double),
+                                 (char *)h->dist_staging + dbytes, Kw * sizeof(double),
+                                 Kw * sizeof(double), prow, hipMemcpyDeviceToDevice, s));
+    }
+    for (int q = 0; q < nsub; ++q)  // replicated: every rank keeps the full z
+      launch_trsv_fwd_step(s, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
+    // trailing update of the block columns this rank owns
+    const int mtE = (int)((npad - CE) / TILE);
+    if (mtE > 0) {
+      const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
+      if (dist_owner(h, P0 + SW) == me)  // next super-panel: its owner updates it first
+        for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
+          launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0,
+                          ld, L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      if (mtE > ntn) {
+        const int64_t C3 = CE + (int64_t)ntn * TILE;
+        const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
+        launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
+                        L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf, 0, 0, &own);
+      }
+    }
+  }
+  launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
+  // alpha by backward substitution (replicated; every rank has the whole factor)
+  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int b = npanel - 1; b >= 0; --b)
+    launch_trsv_bwd_step(s, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  // the failing pivot is only seen by the rank that factored that block: agree on it
+  long long info = 0;
+  memcpy(&info, h->hscal + 8, sizeof info);
+  double flag = (double)info;
+  if (h->dist_allreduce(h->dist_user, &flag, 1) != 0) return fail(h, GOGP_EHIP, "dist: allreduce failed");
+  if (flag != 0.0) {
+    h->notpd = (info != 0) ? (int64_t)info - 1 : (int64_t)flag - 1;
+    h->err = "Factorize: matrix is not positive definite";
+    return GOGP_ENOTPD;
+  }
+  h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * h->hscal[0] - 0.5 * h->hscal[1];
+  h->factored = true;
+  h->have_alpha = true;
+  return GOGP_OK;
+}
+
+// Sharded triangular inverse + the owned tile rows of K^-1 = Y Y^T.
+static int compute_kinv_dist(gogp_handle *h) {
+  if (h->have_kinv) return GOGP_OK;
+  const int64_t npad = h->npad, ld = npad;
+  hipStream_t s = h->s;
+  GemmProfile *pf = &h->prof;
+  if (!h->bufY) HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
+  const int npanel = (int)(npad / PANEL);
+  const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
+  launch_zero_upper_blocks(s, R, ld, npad);
+  for (int P0 = 0; P0 < npanel; P0 += SW) {
+    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
+    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
+    const int owner = dist_owner(h, P0);
+    const size_t ybytes = (size_t)CE * Kw * sizeof(double);  // Y[0:CE, C0:CE]
+    if (owner == me) {
+      for (int q = 0; q < nsub; ++q) {
+        const int p = P0 + q;
+        const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
+        const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+        launch_ydiag(s, Dp, Y + c0 * ld + c0, ld);
+        if (c2 < CE) launch_zero_block(s, Y + c2 * ld + c0, ld, CE - c2, PANEL);
+        if (c0 > 0)
+          launch_dgemm_nt(s, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
+                          Y + c0, ld, pf);
+        if (c2 < CE)
+          launch_dgemm_nt(s, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
+                          Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
+      }
+      HIPCHK(h, hipMemcpy2DAsync(h->dist_staging, Kw * sizeof(double), Y + C0, ld * sizeof(double),
+                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, s));
+    }
+    int rc = dist_bcast(h, (int64_t)ybytes, owner);
+    if (rc != GOGP_OK) return rc;
+    if (owner != me)
+      HIPCHK(h, hipMemcpy2DAsync(Y + C0, ld * sizeof(double), h->dist_staging, Kw * sizeof(double),
+                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, s));
+    const int nt = (int)((npad - CE) / TILE);
+    if (nt > 0) {
+      const int mr = (int)(CE / TILE);
+      const int ntn = nt < 2 * SW ? nt : 2 * SW;
+      if (dist_owner(h, P0 + SW) == me)
+        launch_dgemm_nt(s, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
+                        R + CE, ld, pf);
+      if (nt > ntn) {
+        const int64_t C3 = CE + (int64_t)ntn * TILE;
+        const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
+        launch_dgemm_nt(s, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
+                        R + C3, ld, pf, 0, 0, &own);
+      }
+    }
+  }
+  // K^-1 = Y Y^T: this rank's tile rows only (ti % G == me)
+  const GemmOwn rows = {G, me, 1, 0};
+  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf, 0,
+                  npad, &rows);
+  h->trtri_done = true;
+  h->have_kinv = true;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_dist_setup(gogp_handle *h, int rank, int nranks, gogp_bcast_fn bcast,
+                               gogp_allreduce_fn allreduce, void *user, void *staging,
+                               int64_t staging_bytes) {
+  if (!h) return GOGP_EARG;
+  if (nranks <= 1) {
+    h->dist_n = 1;
+    h->dist_rank = 0;
+    return GOGP_OK;
+  }
+  if (rank < 0 || rank >= nranks || !bcast || !allreduce || !staging)
+    return fail(h, GOGP_EARG, "dist_setup: bad arguments");
+  h->dist_rank = rank;
+  h->dist_n = nranks;
+  h->dist_bcast = bcast;
+  h->dist_allreduce = allreduce;
+  h->dist_user = user;
+  h->dist_staging = (double *)staging;
+  h->dist_staging_bytes = staging_bytes;
+  h->factored = h->observed = h->grad_valid = h->have_kinv = false;
+  return GOGP_OK;
+}
+
 static int set_theta_natural(gogp_handle *h, const double *ts, const double *tn) {
   for (int i = 0; i < h->ns; ++i) {
     if (!(ts[i] > 0.0) || !std::isfinite(ts[i]))
@@ -623,7 +835,7 @@ extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
     h->factored = false;
     return GOGP_OK;
   }
-  rc = factorize(h, false);
+  rc = (h->dist_n > 1) ? factorize_dist(h) : factorize(h, false);
   if (rc != GOGP_OK) return rc;
   rc = ensure_alpha(h);  // gp/gp.go:232-236
   if (rc != GOGP_OK) return rc;
@@ -645,7 +857,8 @@ static int observe_theta(gogp_handle *h, const double *x, double *lml) {
     if (lml) *lml = 0.0;
     return GOGP_OK;
   }
-  rc = factorize(h, h->eager != 0);  // gp/gp.go:402 (always with gradient preparation)
+  rc = (h->dist_n > 1) ? factorize_dist(h)
+                       : factorize(h, h->eager != 0);  // gp/gp.go:402 (with gradient preparation)
   if (rc != GOGP_OK) return rc;
   h->observed = true;
   if (lml) *lml = h->lml;  // gp/gp.go:412
@@ -727,17 +940,21 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
   for (int64_t i = 0; i < len; ++i) grad[i] = 0.0;
   if (h->n == 0) return GOGP_OK;  // gp/gp.go:427-430
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->dist_n > 1 && h->with_obs)
+    return fail(h, GOGP_EARG, "sharded evaluation: the full Observe form is not supported");
   if (!h->grad_valid) {
-    int rc = compute_kinv(h);
+    int rc = (h->dist_n > 1) ? compute_kinv_dist(h) : compute_kinv(h);
     if (rc != GOGP_OK) return rc;
     rc = ensure_alpha(h);
     if (rc != GOGP_OK) return rc;
     hipStream_t s = h->s;
     launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
-                       h->npad, h->gpart, h->gout);
+                       h->npad, h->gpart, h->gout, h->dist_n, h->dist_rank);
     HIPCHK(h, hipMemcpyAsync(h->hscal + 16, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
+    if (h->dist_n > 1 && h->dist_allreduce(h->dist_user, h->hscal + 16, NACC) != 0)
+      return fail(h, GOGP_EHIP, "dist: allreduce failed");
     const double *a = h->hscal + 16;
     h->grad_cache.assign(h->P, 0.0);
     const gogp_desc &d = h->desc;

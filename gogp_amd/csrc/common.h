@@ -44,6 +44,13 @@ struct GemmProfile {
   int64_t launches = 0;
 };
 
+// Ownership filter for the tile kernel in a sharded evaluation (see GemmArgs):
+// n ranks, this rank r, tiles_per_sp 128-wide tile columns per super-panel, col0 =
+// global index of the launch's first 128-wide tile column.
+struct GemmOwn {
+  int n, r, tiles_per_sp, col0;
+};
+
 // ---- launchers implemented in the .hip files ------------------------------
 enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2 };
 
@@ -54,7 +61,8 @@ enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2 };
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
                      double alpha, const double *A, int64_t lda, const double *B,
                      int64_t ldb, double beta, double *C, int64_t ldc,
-                     GemmProfile *prof, int64_t kskip = 0, int64_t kend = 0);
+                     GemmProfile *prof, int64_t kskip = 0, int64_t kend = 0,
+                     const GemmOwn *own = nullptr);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
@@ -100,7 +108,7 @@ int grad_reduce_blocks(int64_t npad);
 // fused gradient reduction over lower tiles of Kinv; out: NACC doubles
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
-                        int64_t npad, double *partials, double *out);
+                        int64_t npad, double *partials, double *out, int own_n = 0, int own_r = 0);
 
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}

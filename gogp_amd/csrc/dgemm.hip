@@ -40,6 +40,11 @@ struct GemmArgs {
   // GEMM_LAUUM only: the K range of tile (ti,tj) is [max(ti*BT, kskip), kend); tiles
   // whose range starts below kskip accumulate (beta = 1), the others overwrite
   int kskip, kend;
+  // Ownership filter of a sharded evaluation (own_n <= 1: none).  RECT / LOWER: a tile
+  // is computed iff its block column belongs to this rank, i.e.
+  // ((own_col0 + tj) / own_tps) % own_n == own_r  (tile columns counted in units of
+  // this kernel's tile, own_tps tiles per super-panel).  LAUUM: iff ti % own_n == own_r.
+  int own_n, own_r, own_tps, own_col0;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -78,6 +83,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     while (ti * (ti + 1) / 2 > t) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
+  }
+  if (g.own_n > 1) {  // workgroup-uniform early exit for tiles of other ranks
+    if (MODE == GEMM_LAUUM) {
+      if (ti % g.own_n != g.own_r) return;
+    } else if (((g.own_col0 + tj) / g.own_tps) % g.own_n != g.own_r) {
+      return;
+    }
   }
   int kbeg = 0, nkt = g.nkt;
   double beta = g.beta;
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
                      const double *A, int64_t lda, const double *B, int64_t ldb,
                      double beta, double *C, int64_t ldc, GemmProfile *prof, int64_t kskip,
-                     int64_t kend) {
+                     int64_t kend, const GemmOwn *own) {
   if (mt <= 0 || nt <= 0 || K <= 0) return;
   GemmArgs g;
   g.A = A;
@@ -224,6 +236,10 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   if (kend <= 0 || kend > K) kend = K;
   g.kskip = (int)kskip;
   g.kend = (int)kend;
+  g.own_n = own ? own->n : 0;
+  g.own_r = own ? own->r : 0;
+  g.own_tps = own ? own->tiles_per_sp : 1;
+  g.own_col0 = own ? own->col0 : 0;
   int ntiles;
   double flops;
   if (mode == GEMM_RECT) {
@@ -262,6 +278,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   if (small) {
     g.mt = mt * 2;
     g.nt = nt * 2;
+    g.own_tps *= 2;  // ownership counted in 64-wide tile columns
+    g.own_col0 *= 2;
     const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
     dim3 grid(n64);
     if (mode == GEMM_RECT)

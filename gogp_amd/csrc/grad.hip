@@ -21,7 +21,7 @@ template <int ARD_D>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
     const double *__restrict__ alpha, const double *__restrict__ Kinv, long ld, long n, int nt,
-    int ntiles, double *__restrict__ partials) {
+    int ntiles, double *__restrict__ partials, int own_n, int own_r) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
     while (ti * (ti + 1) / 2 > t) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
+    // sharded evaluation: only the 128-row tile rows of K^-1 this rank computed
+    if (own_n > 1 && ((ti >> 1) % own_n) != own_r) continue;
     const long r0 = (long)ti * 64, c0 = (long)tj * 64;
     __syncthreads();  // previous tile's readers are done
     for (int idx = tid; idx < 64 * D; idx += 256) {
@@ -123,14 +125,15 @@ int grad_reduce_blocks(int64_t npad) {
 
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out) {
+                        int64_t n, int64_t npad, double *partials, double *out, int own_n,
+                        int own_r) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GR(AD)                                                                      \
   hipLaunchKernelGGL(grad_reduce_kernel<AD>, dim3(blocks), dim3(256), lds, s, p, X, alpha, Kinv, \
-                     (long)ld, (long)n, nt, ntiles, partials)
+                     (long)ld, (long)n, nt, ntiles, partials, own_n, own_r)
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
   else if (ard_dims <= 16) GOGP_LAUNCH_GR(16);

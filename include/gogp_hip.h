@@ -182,6 +182,29 @@ int gogp_set_factor(gogp_handle *h, const double *theta_simil,
                     const double *theta_noise, const double *L /* n*n */,
                     const double *alpha /* n */);
 
+/* ---- one evaluation sharded over several GPUs ----------------------------------
+ * One process per GPU; every rank holds the full X, y and calls the SAME sequence of
+ * gogp_observe / gogp_gradient collectively.  The blocked factorisation is sharded
+ * 1-D block-cyclically by 512-wide super-panels of columns: the owner of a
+ * super-panel factors it and broadcasts the packed panel; every rank applies the
+ * trailing update only to the block columns it owns; the triangular inverse is
+ * sharded the same way, K^-1 = Y Y^T and the gradient reduction by tile rows, with
+ * one all-reduce of the partial gradient sums.  The reference has no counterpart
+ * (single process, goroutines only: gp/gp.go:165-213).
+ *
+ * Communication goes through two callbacks supplied by the host layer (RCCL via
+ * torch.distributed on a real node, gloo for rehearsals):
+ *   bcast(user, dev_buf, bytes, root): broadcast `bytes` of the staging buffer
+ *     (device memory) from rank `root`; must return after the data have arrived;
+ *   allreduce(user, host_buf, count): sum `count` host doubles over the ranks in place.
+ * `staging` is a device buffer the host layer owns (>= gogp_dist_staging_bytes). */
+typedef int (*gogp_bcast_fn)(void *user, void *dev_buf, int64_t bytes, int root);
+typedef int (*gogp_allreduce_fn)(void *user, double *host_buf, int64_t count);
+int64_t gogp_dist_staging_bytes(int64_t n);
+int gogp_dist_setup(gogp_handle *h, int rank, int nranks, gogp_bcast_fn bcast,
+                    gogp_allreduce_fn allreduce, void *user, void *staging,
+                    int64_t staging_bytes);
+
 /* ---- measurement hooks (bench.py / tests; not part of the reference API) --- */
 
 /* Enable (1) / disable (0) HIP-event timing of every launch of the dominant
