@@ -615,17 +615,27 @@ extern "C" int64_t gogp_dist_staging_bytes(int64_t n) {
   return (npad * 4 * PANEL + 4 * (int64_t)PANEL * PANEL) * (int64_t)sizeof(double);
 }
 
+// Host-synchronous broadcast of the staging buffer.  Only the PANEL stream is
+// drained first (it carries the owner's chain + packing, and the previous unpack
+// that last read the staging buffer); the main stream keeps running its trailing
+// updates underneath the broadcast.
 static int dist_bcast(gogp_handle *h, int64_t bytes, int root) {
   if (bytes > h->dist_staging_bytes) return fail(h, GOGP_EARG, "dist: staging buffer too small");
-  HIPCHK(h, hipStreamSynchronize(h->s));
+  HIPCHK(h, hipStreamSynchronize(h->sp));
   if (h->dist_bcast(h->dist_user, h->dist_staging, bytes, root) != 0)
     return fail(h, GOGP_EHIP, "dist: broadcast callback failed");
   return GOGP_OK;
 }
 
+// Streams: sp = owner's chain (diagonal blocks, panel solves), packing, unpacking,
+// replicated substitution steps; s = trailing updates of the owned block columns.
+// Per super-panel P:  [sp, owner] wait "my column is up to date" -> chain -> pack;
+// [host] drain sp, broadcast; [sp, others] unpack; [s] wait "panel P complete" ->
+// next owner's block columns first -> event -> the rest of my columns.  The chain and
+// the broadcast of P+1 therefore overlap the rest-update of P on every rank.
 static int factorize_dist(gogp_handle *h) {
   const int64_t npad = h->npad, ld = npad;
-  hipStream_t s = h->s;
+  hipStream_t s = h->s, sp = h->sp;
   for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_pending = false;
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
@@ -639,11 +649,12 @@ static int factorize_dist(gogp_handle *h) {
   // every rank builds the whole lower triangle (0.5 ms at N = 16384); it only ever
   // reads the block columns it owns
   launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
+  order(h, EV_GRAM, s, sp);
   double *A = h->bufA, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
   const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
-  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
   for (int P0 = 0; P0 < npanel; P0 += SW) {
     const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
     const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
@@ -653,36 +664,40 @@ static int factorize_dist(gogp_handle *h) {
     const int64_t prow = npad - C0;  // packed panel rows C0 .. npad
     const size_t pbytes = (size_t)prow * Kw * sizeof(double);
     if (owner == me) {
+      // my block columns [C0, CE) are up to date once my "next columns" update of the
+      // previous super-panel is done
+      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
       for (int q = 0; q < nsub; ++q) {
         const int p = P0 + q;
         const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
         double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-        launch_diag256(s, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+        launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
         const int mt2 = (int)((npad - c2) / TILE);
         if (mt2 > 0)
-          launch_dgemm_nt(s, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
+          launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
                           L + c2 * ld + c0, ld, pf);
         for (int64_t cr = c2; cr < CE; cr += PANEL)
-          launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0,
+          launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0,
                           L + cr * ld + c0, ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
       }
       // pack [diagonal inverses | L[C0:npad, C0:CE]] into the staging buffer
-      HIPCHK(h, hipMemcpyAsync(h->dist_staging, Dp0, dbytes, hipMemcpyDeviceToDevice, s));
+      HIPCHK(h, hipMemcpyAsync(h->dist_staging, Dp0, dbytes, hipMemcpyDeviceToDevice, sp));
       HIPCHK(h, hipMemcpy2DAsync((char *)h->dist_staging + dbytes, Kw * sizeof(double),
                                  L + C0 * ld + C0, ld * sizeof(double), Kw * sizeof(double), prow,
-                                 hipMemcpyDeviceToDevice, s));
+                                 hipMemcpyDeviceToDevice, sp));
     }
     rc = dist_bcast(h, (int64_t)(dbytes + pbytes), owner);
     if (rc != GOGP_OK) return rc;
     if (owner != me) {
-      HIPCHK(h, hipMemcpyAsync(Dp0, h->dist_staging, dbytes, hipMemcpyDeviceToDevice, s));
+      HIPCHK(h, hipMemcpyAsync(Dp0, h->dist_staging, dbytes, hipMemcpyDeviceToDevice, sp));
       HIPCHK(h, hipMemcpy2DAsync(L + C0 * ld + C0, ld * sizeof(double),
                                  (char *)h->dist_staging + dbytes, Kw * sizeof(double),
-                                 Kw * sizeof(double), prow, hipMemcpyDeviceToDevice, s));
+                                 Kw * sizeof(double), prow, hipMemcpyDeviceToDevice, sp));
     }
-    for (int q = 0; q < nsub; ++q)  // replicated: every rank keeps the full z
-      launch_trsv_fwd_step(s, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
-    // trailing update of the block columns this rank owns
+    order(h, EV_BASE + 4 * P0, sp, s);  // panel P complete on this rank
+    for (int q = 0; q < nsub; ++q)       // replicated: every rank keeps the full z
+      launch_trsv_fwd_step(sp, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
+    // trailing update of the block columns this rank owns (main stream)
     const int mtE = (int)((npad - CE) / TILE);
     if (mtE > 0) {
       const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
@@ -690,6 +705,7 @@ static int factorize_dist(gogp_handle *h) {
         for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
           launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0,
                           ld, L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
@@ -698,6 +714,7 @@ static int factorize_dist(gogp_handle *h) {
       }
     }
   }
+  order(h, EV_FWD, sp, s);
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -706,6 +723,7 @@ static int factorize_dist(gogp_handle *h) {
   for (int b = npanel - 1; b >= 0; --b)
     launch_trsv_bwd_step(s, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
   HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipStreamSynchronize(sp));
   HIPCHK(h, hipGetLastError());
   // the failing pivot is only seen by the rank that factored that block: agree on it
   long long info = 0;
@@ -723,44 +741,49 @@ static int factorize_dist(gogp_handle *h) {
   return GOGP_OK;
 }
 
-// Sharded triangular inverse + the owned tile rows of K^-1 = Y Y^T.
+// Sharded triangular inverse + the owned tile rows of K^-1 = Y Y^T; same two-stream
+// scheme as factorize_dist (sp: owner's column panel of Y, pack / unpack; s: updates).
 static int compute_kinv_dist(gogp_handle *h) {
   if (h->have_kinv) return GOGP_OK;
   const int64_t npad = h->npad, ld = npad;
-  hipStream_t s = h->s;
+  hipStream_t s = h->s, sp = h->sp;
   GemmProfile *pf = &h->prof;
   if (!h->bufY) HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
   double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   const int npanel = (int)(npad / PANEL);
   const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
   launch_zero_upper_blocks(s, R, ld, npad);
+  order(h, EV_INIT, s, sp);
   for (int P0 = 0; P0 < npanel; P0 += SW) {
     const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
     const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
     const int owner = dist_owner(h, P0);
     const size_t ybytes = (size_t)CE * Kw * sizeof(double);  // Y[0:CE, C0:CE]
     if (owner == me) {
+      // R[0:C0, C0:CE] is final once my "next columns" update of the previous step is done
+      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 3), 0);
       for (int q = 0; q < nsub; ++q) {
         const int p = P0 + q;
         const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
         const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-        launch_ydiag(s, Dp, Y + c0 * ld + c0, ld);
-        if (c2 < CE) launch_zero_block(s, Y + c2 * ld + c0, ld, CE - c2, PANEL);
+        launch_ydiag(sp, Dp, Y + c0 * ld + c0, ld);
+        if (c2 < CE) launch_zero_block(sp, Y + c2 * ld + c0, ld, CE - c2, PANEL);
         if (c0 > 0)
-          launch_dgemm_nt(s, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
+          launch_dgemm_nt(sp, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
                           Y + c0, ld, pf);
         if (c2 < CE)
-          launch_dgemm_nt(s, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
+          launch_dgemm_nt(sp, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
                           Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
       }
       HIPCHK(h, hipMemcpy2DAsync(h->dist_staging, Kw * sizeof(double), Y + C0, ld * sizeof(double),
-                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, s));
+                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, sp));
     }
     int rc = dist_bcast(h, (int64_t)ybytes, owner);
     if (rc != GOGP_OK) return rc;
     if (owner != me)
       HIPCHK(h, hipMemcpy2DAsync(Y + C0, ld * sizeof(double), h->dist_staging, Kw * sizeof(double),
-                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, s));
+                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, sp));
+    order(h, EV_BASE + 4 * P0 + 2, sp, s);  // column panel P of Y complete on this rank
     const int nt = (int)((npad - CE) / TILE);
     if (nt > 0) {
       const int mr = (int)(CE / TILE);
@@ -768,6 +791,7 @@ static int compute_kinv_dist(gogp_handle *h) {
       if (dist_owner(h, P0 + SW) == me)
         launch_dgemm_nt(s, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
                         R + CE, ld, pf);
+      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s);
       if (nt > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};

@@ -26,7 +26,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 ok = True
 for (n, D, simil) in [(700, 3, kernel.Scaled(kernel.Normal)), (1500, 2, kernel.Scaled(kernel.Matern52)),
-                      (2300, 4, kernel.Scaled(kernel.ARD(kernel.Normal, 4)))]:
+                      (2300, 4, kernel.Scaled(kernel.ARD(kernel.Normal, 4))),
+                      (5000, 2, kernel.Scaled(kernel.Normal))]:
     X, y = synth.make_inputs(n, D, 1234 + n)
     nth = simil.NTheta() + 1
     x = np.log(np.linspace(0.6, 1.2, nth))
@@ -65,7 +66,7 @@ open(os.path.join(%(out)r, "rank%%d.ok" %% rank), "w").write("ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_evaluation_matches_single_gpu(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
