@@ -13,13 +13,19 @@
 // Reference counterpart: gonum's Dpotrf/Dpotri/Dtrsm/Dgemm behind
 // mat.Cholesky.Factorize / SolveTo (call sites gp/gp.go:228,338,454,480).
 //
-// Structure (CDNA4): 256 threads = 4 waves, each wave owns a 64x64 sub-tile as
-// 4x4 MFMA 16x16 accumulators (128 acc VGPRs).  K is walked in steps of 16:
+// Structure (CDNA4): a 128x128 tile per workgroup in two wave shapes.  Large launches
+// use 512 threads = 8 waves of 64x32 outputs (4x2 MFMA 16x16 accumulators, 64 acc
+// VGPRs, <= 128 VGPRs in all): two workgroups per CU put FOUR waves on every SIMD,
+// which hides the barrier / prologue / epilogue bubbles of any one of them.  Mid-size
+// launches use 256 threads = 4 waves of 64x64 (128 acc VGPRs, two waves per SIMD), and
+// the skinny GEMMs of the panel chain a 64x64 tile.  K is walked in steps of 16:
 // both operand tiles (128 rows x 16 doubles = one 128-B line per row) are
 // staged global -> registers -> LDS, double-buffered, one barrier per step.
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so
 // that the MFMA fragment reads (16 rows x 2 k per 32-lane group, ds_read_b64)
 // hit 32 distinct 8-B bank pairs: conflict-free.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -52,13 +58,17 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 1);
 }
 
-// BT = workgroup tile (128 or 64).  Always 4 waves in a 2x2 arrangement; each
-// wave owns (BT/2)x(BT/2) outputs = MT x MT MFMA tiles, MT = BT/32.
-template <int MODE, int BT>
-__global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
-  constexpr int MT = BT / 32;       // MFMA tiles per wave per dimension
-  constexpr int WT = BT / 2;        // rows/cols per wave
-  constexpr int NQ = BT / 32;       // staging loads per thread per operand
+// BT = workgroup tile (128 or 64).  NW = 4: 2x2 waves, each (BT/2)x(BT/2) outputs =
+// MT x MT MFMA tiles, MT = BT/32.  NW = 8 (BT = 128): 2x4 waves, each 64x32 outputs:
+// half the accumulators per wave (<= 128 VGPRs), so four waves fit on a SIMD.
+template <int MODE, int BT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
+  constexpr int MT = BT / 32;                          // MFMA tiles per wave, rows
+  constexpr int NTW = (NW == 8) ? BT / 64 : BT / 32;   // MFMA tiles per wave, columns
+  constexpr int WT = BT / 2;                           // rows per wave
+  constexpr int WTN = (NW == 8) ? BT / 4 : BT / 2;     // columns per wave
+  constexpr int NQ = BT * 8 / (NW * 64);               // staging loads per thread per operand
+  constexpr int SROWS = NW * 8;                        // rows one staging pass covers
   __shared__ __attribute__((aligned(16))) double lds[2][2][BT * GEMM_BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -107,30 +117,33 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
   const double *Bg = g.B + (long)tj * BT * g.ldb + kbeg;
 
   // ---- staging map: thread -> (row, 16-B chunk), NQ rows per operand --------
-  const int srow = tid >> 3;  // 0..31, +32*q
+  const int srow = tid >> 3;  // 0..SROWS-1, +SROWS*q
   const int schunk = tid & 7;
   const double *Ap = Ag + (long)srow * g.lda + schunk * 2;
   const double *Bp = Bg + (long)srow * g.ldb + schunk * 2;
-  const long a_step = 32 * g.lda, b_step = 32 * g.ldb;
+  const long a_step = (long)SROWS * g.lda, b_step = (long)SROWS * g.ldb;
   int soff[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) soff[q] = lds_off(srow + 32 * q, schunk);
+  for (int q = 0; q < NQ; ++q) soff[q] = lds_off(srow + SROWS * q, schunk);
 
   // ---- fragment map --------------------------------------------------------
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = (NW == 8) ? wid >> 2 : wid >> 1;
+  const int wc = (NW == 8) ? wid & 3 : wid & 1;
   const int frow = lane & 15;
   const int fk = lane >> 4;      // k within an MFMA step: 0..3
   const int fchunk = fk >> 1;    // + 2*kk
   const int fhalf = fk & 1;
-  int arow[MT], brow[MT];
+  // LDS offset of fragment (m, kk) = base + m * (16 rows) + xk[kk]: the swizzle term
+  // (row >> 1) & 7 only depends on frow (wave and MFMA-tile row offsets are multiples
+  // of 16), so the m / n steps are immediate offsets of the ds_read
+  const int abase = (wr * WT + frow) * GEMM_BK;
+  const int bbase = (wc * WTN + frow) * GEMM_BK;
+  int xk[4];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    arow[m] = wr * WT + m * 16 + frow;
-    brow[m] = wc * WT + m * 16 + frow;
-  }
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = (((kk * 2 + fchunk) ^ ((frow >> 1) & 7)) << 1) + fhalf;
 
   // C fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
+  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WTN;
   const int ccol = lane & 15;
   const int crow = lane >> 4;
   const double alpha = g.alpha;
@@ -144,13 +157,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
     rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
   }
-  f64x4 acc[MT][MT];
+  f64x4 acc[MT][NTW];
   if (beta != 0.0) {
     const double sc = beta / alpha;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < MT; ++n)
+      for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
           acc[m][n][v] = sc * Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol];
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < MT; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      for (int n = 0; n < NTW; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -183,16 +196,15 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
     const double *lb = lds[cur][1];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double a[MT], b[MT];
+      double a[MT], b[NTW];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        a[m] = la[lds_off(arow[m], kk * 2 + fchunk) + fhalf];
-        b[m] = lb[lds_off(brow[m], kk * 2 + fchunk) + fhalf];
-      }
+      for (int m = 0; m < MT; ++m) a[m] = la[abase + m * 16 * GEMM_BK + xk[kk]];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) b[n] = lb[bbase + n * 16 * GEMM_BK + xk[kk]];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < MT; ++n)
+        for (int n = 0; n < NTW; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
     if (more) {
@@ -210,11 +222,18 @@ __global__ __launch_bounds__(256, 2) void dgemm_nt_kernel(GemmArgs g) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < MT; ++n)
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol] = alpha * acc[m][n][v];
 }
+
+// GOGP_GEMM_W8 = 0 / 1 forces the 4-wave / 8-wave 128-tile kernel (A/B measurements);
+// unset: 8 waves for the large launches, where they measured 4-9% faster.
+static const int g_gemm_w8 = [] {
+  const char *e = getenv("GOGP_GEMM_W8");
+  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}();
 
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
                      const double *A, int64_t lda, const double *B, int64_t ldb,
@@ -283,20 +302,33 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
     dim3 grid(n64);
     if (mode == GEMM_RECT)
-      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64>), grid, block, 0, s, g);
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4>), grid, block, 0, s, g);
     else
-      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64>), grid, block, 0, s, g);
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4>), grid, block, 0, s, g);
+  } else if (g_gemm_w8 == 1 || (g_gemm_w8 < 0 && (mode == GEMM_LAUUM || ntiles >= 3072))) {
+    dim3 grid(ntiles), block8(512);
+    switch (mode) {
+      case GEMM_RECT:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8>), grid, block8, 0, s, g);
+        break;
+      case GEMM_LOWER:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8>), grid, block8, 0, s, g);
+        break;
+      case GEMM_LAUUM:
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8>), grid, block8, 0, s, g);
+        break;
+    }
   } else {
     dim3 grid(ntiles);
     switch (mode) {
       case GEMM_RECT:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4>), grid, block, 0, s, g);
         break;
       case GEMM_LOWER:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4>), grid, block, 0, s, g);
         break;
       case GEMM_LAUUM:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128>), grid, block, 0, s, g);
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4>), grid, block, 0, s, g);
         break;
     }
   }
