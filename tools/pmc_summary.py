@@ -2,8 +2,9 @@
 import collections, csv, glob, sys
 
 def short(n):
-    for k in ['dgemm_nt_kernel<0, 64>', 'dgemm_nt_kernel<1, 64>', 'dgemm_nt_kernel<0, 128>', 'dgemm_nt_kernel<1, 128>',
-              'dgemm_nt_kernel<2, 128>', 'diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y',
+    for k in ['dgemm_nt_kernel<0, 64, 4>', 'dgemm_nt_kernel<1, 64, 4>', 'dgemm_nt_kernel<0, 128, 4>',
+              'dgemm_nt_kernel<1, 128, 4>', 'dgemm_nt_kernel<2, 128, 4>', 'dgemm_nt_kernel<0, 128, 8>',
+              'dgemm_nt_kernel<1, 128, 8>', 'dgemm_nt_kernel<2, 128, 8>', 'diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y',
               'zero_upper', 'mfma_f64_peak']:
         if k in n:
             return k
