@@ -56,7 +56,7 @@ def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
     os.environ["OMP_NUM_THREADS"] = str(cores)  # before the C oracle (libgomp) is loaded
     from threadpoolctl import threadpool_limits
     from gogp_amd import kernel, synth
-    from oracle.oracle import FastOracle  # checker / baseline only
+    from oracle.oracle import FastOracle, Oracle  # checker / baseline only
     threadpool_limits(limits=cores)
     X, y = synth.make_inputs(N, D, seed)
     Xs, ys = X[:sample_n], y[:sample_n]
@@ -79,10 +79,29 @@ def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
                   % (sample_n, D, dt, sample_n, N, N),
         "measured_evals_per_s_at_sample": 1.0 / dt,
     }
-    lml_gpu, g_gpu = lml_gpu_fn(Xs, ys, x)
+    # the reference's own algorithm (dense dK per parameter, r0 = aa^T dK, r1 = K^-1 dK:
+    # gp/gp.go:476-485; 4P N^3 flop) as restated by the faithful C oracle, single thread,
+    # at a size it finishes in about a second, extrapolated by its N^3 law
+    nf = min(512, sample_n)
+    of = Oracle(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise)
+    of.set_data(X[:nf], y[:nf])
+    t0 = time.time()
+    of.Observe(x)
+    of.Gradient()
+    dtf = time.time() - t0
+    out["faithful_algorithm"] = {
+        "n": nf, "cores": 1, "seconds": dtf,
+        "extrapolated_evals_per_s": (1.0 / dtf) * (nf / float(N)) ** 3,
+        "note": "dense-dK algorithm of gp/gp.go:418-499 in C (no AD tape, no Go runtime), "
+                "scaled by (n/N)^3"}
+    Z = synth.make_test_points(1024, D, seed + 1)
+    mu, sigma = o.Produce(Z)
+    lml_gpu, g_gpu, mu_gpu, sigma_gpu = lml_gpu_fn(Xs, ys, x, Z)
     rel = abs(lml_gpu - lml) / abs(lml)
     grel = float(np.abs(g_gpu - g).max() / max(1.0, np.abs(g).max()))
-    return out, rel, grel
+    murel = float(np.abs(mu_gpu - mu).max() / max(1e-300, np.abs(mu).max()))
+    sgrel = float(np.abs(sigma_gpu - sigma).max() / max(1e-300, np.abs(sigma).max()))
+    return out, rel, grel, murel, sgrel
 
 
 def main():
@@ -204,6 +223,19 @@ def main():
                         "sustained v_mfma_f64 issue-rate microbenchmark on this device",
             },
         }
+        if world == 1:
+            # secondary metric: Produce throughput at the same N, M = 1024 fresh
+            # test points per call, host Z in / host mu, sigma out -- outside the timed region
+            Zp = synth.make_test_points(1024, D, seed + 1)
+            g.Produce(Zp)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(3):
+                mu_p, sigma_p = g.Produce(Zp)
+            tp = (time.perf_counter() - tp) / 3
+            out["produce"] = {"m": 1024, "ms_per_call": tp * 1e3, "test_points_per_s": 1024 / tp,
+                              "note": "Kstar build + mu = Kstar^T alpha + blocked solve V^T = Kstar^T L^-T "
+                                      "(N^2 M flop on the tile kernel) + column norms, factor resident"}
         out_holder = out
     else:
         out_holder = None
@@ -259,16 +291,19 @@ def main():
         if sharded is not None:
             out["sharded_evaluation"] = sharded
         if world == 1 and not args.no_cpu_baseline:
-            def lml_gpu_fn(Xs, ys, x):
+            def lml_gpu_fn(Xs, ys, x, Z):
                 g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank)
                 v = g2.Observe(x)
                 gr = g2.Gradient()
+                mu, sigma = g2.Produce(Z)
                 g2.close()
-                return v, gr
-            cb, rel, grel = cpu_baseline(N, D, seed, min(args.cpu_sample_n, N), lml_gpu_fn)
+                return v, gr, mu, sigma
+            cb, rel, grel, murel, sgrel = cpu_baseline(N, D, seed, min(args.cpu_sample_n, N), lml_gpu_fn)
             out["cpu_baseline"] = cb
             out["lml_rel_err_vs_oracle"] = rel
             out["grad_rel_err_vs_oracle"] = grel
+            out["mu_rel_err_vs_oracle"] = murel
+            out["sigma_rel_err_vs_oracle"] = sgrel
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

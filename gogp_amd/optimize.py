@@ -153,3 +153,31 @@ class NormalLogPriors:
 
     def Gradient(self) -> np.ndarray:
         return -(self._x - self.mean) / (self.std ** 2)
+
+
+class Adam:
+    """infer.Adam{Rate: r} as the tutorial uses it (tutorial/tutorial.go:156-168): ``Step(m, x)``
+    evaluates the model, moves x IN PLACE one Adam step UP the log-likelihood gradient and
+    returns (log-likelihood, gradient) at the point it evaluated.  infergo v1.2.2 is not in
+    the container; the update is the published Adam rule with its usual defaults
+    (beta1 0.9, beta2 0.999, eps 1e-8) -- iterate-by-iterate parity is unpinned."""
+
+    def __init__(self, Rate: float = 0.01, Beta1: float = 0.9, Beta2: float = 0.999, Eps: float = 1e-8):
+        self.Rate, self.Beta1, self.Beta2, self.Eps = Rate, Beta1, Beta2, Eps
+        self._m = None
+        self._v = None
+        self._t = 0
+
+    def Step(self, m, x):
+        ll = m.Observe(x)
+        grad = np.asarray(m.Gradient(), dtype=float)
+        if self._m is None:
+            self._m = np.zeros_like(grad)
+            self._v = np.zeros_like(grad)
+        self._t += 1
+        self._m = self.Beta1 * self._m + (1 - self.Beta1) * grad
+        self._v = self.Beta2 * self._v + (1 - self.Beta2) * grad * grad
+        mhat = self._m / (1 - self.Beta1 ** self._t)
+        vhat = self._v / (1 - self.Beta2 ** self._t)
+        x += self.Rate * mhat / (np.sqrt(vhat) + self.Eps)
+        return ll, grad

@@ -128,21 +128,7 @@ def _data(rng, n, D):
     return X, y
 
 
-CASES = [
-    ("normal1d", 1, kernel.Normal, kernel.ConstantNoise(0.1), [0.3], []),
-    ("scaled_rbf", 4, kernel.Scaled(kernel.Normal), kernel.UniformNoise, [1.0, 0.8], [0.1]),
-    ("ard_rbf", 5, kernel.Scaled(kernel.ARD(kernel.Normal, 5)), kernel.UniformNoise,
-     [1.2, 0.9, 1.0, 1.1, 1.2, 1.3], [0.2]),
-    ("matern32", 2, kernel.Scaled(kernel.Matern32), kernel.ScaledNoise(0.01), [1.0, 0.7], [1.5]),
-    ("matern52_ref", 3, kernel.Scaled(kernel.Matern52), kernel.UniformNoise, [0.9, 1.1], [0.15]),
-    ("matern52_textbook", 3, kernel.Scaled(kernel.Matern52Textbook), kernel.UniformNoise,
-     [0.9, 1.1], [0.15]),
-    ("periodic", 1, kernel.Scaled(kernel.Periodic), kernel.UniformNoise, [1.0, 0.8, 0.45], [0.2]),
-    ("hyperpriors", 1,
-     kernel.Sum([kernel.Scaled(kernel.Matern52), kernel.Scaled(kernel.PeriodScaled(kernel.Periodic, 10.0))],
-                order=[0, 2, 1, 3, 4]), kernel.ScaledNoise(0.01), [1.0, 0.5, 0.6, 1.3, 0.05], [2.0]),
-    ("default_noise", 2, kernel.Scaled(kernel.Matern32), None, [1.0, 0.3], []),
-]
+from cases import CASES  # noqa: E402  (shared with tests/golden/make_oracle_vectors.py)
 
 
 def _check_against(gpmod, oracle_cls, name, D, simil, noise, ts, tn, n, m, seed,
@@ -174,6 +160,31 @@ def test_small_vs_faithful_oracle(gpmod, name, D, simil, noise, ts, tn):
     from oracle.oracle import Oracle
     g, o = _check_against(gpmod, Oracle, name, D, simil, noise, ts, tn, n=50, m=9, seed=7)
     np.testing.assert_allclose(g.L, o.L, rtol=1e-8, atol=1e-10)
+
+
+def test_oracle_vectors(gpmod, golden_dir):
+    """HIP path against the committed oracle regression vectors (every kernel family
+    at N in {2, 20, 64, 256, 1024}; tests/golden/make_oracle_vectors.py)."""
+    from gogp_amd import synth
+    with open(os.path.join(golden_dir, "oracle_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    cases = {c[0]: c for c in CASES}
+    assert len(vectors) == 5 * len(CASES)
+    for v in vectors:
+        _, D, simil, noise, _, _ = cases[v["case"]]
+        X, y = synth.make_inputs(v["n"], D, v["seed"])
+        Z = synth.make_test_points(v["m"], D, v["seed"] + 1)
+        assert X.sum() == v["x_sum"] and y.sum() == v["y_sum"] and Z.sum() == v["z_sum"]
+        g = gpmod.GP(D, simil, noise, X=X, Y=y)
+        tag = (v["case"], v["n"])
+        lml = g.Observe(np.array(v["log_theta"]))
+        assert abs(lml - v["lml"]) <= 1e-8 * max(1.0, abs(v["lml"])), (tag, lml, v["lml"])
+        grad, want = g.Gradient(), np.array(v["grad"])
+        assert np.abs(grad - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (tag, grad, want)
+        mu, sigma = g.Produce(Z)
+        np.testing.assert_allclose(mu, v["mu"], rtol=1e-6, atol=1e-7, err_msg=str(tag))
+        np.testing.assert_allclose(sigma, v["sigma"], rtol=1e-6, atol=1e-6, err_msg=str(tag))
+        g.close()
 
 
 @pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 255, 256, 257, 700])
