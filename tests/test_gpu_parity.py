@@ -391,6 +391,56 @@ def test_config3_full_size_properties(gpmod):
     assert np.isfinite(lml)
 
 
+@pytest.mark.parametrize("shape", ["config4", "config5"])
+def test_config4_config5_shapes_full_size_properties(gpmod, shape):
+    """The shapes of BASELINE configs 4 (Matern-5/2, reference coefficient, N=32768, D=16) and
+    5 (ARD-RBF, N=65536, D=32, P=34; in fp64 -- there is no fp32 path yet) on ONE GPU, through
+    the same size-independent properties as config 3: K alpha = y on sampled rows rebuilt on
+    the host, gradient against a central difference of the LML along a random direction,
+    and Produce at training inputs (mu_i = y_i - s2 alpha_i)."""
+    from gogp_amd import synth
+    if shape == "config4":
+        N, D = 32768, 16
+        simil = kernel.Scaled(kernel.Matern52)
+        th = np.array([1.0, math.sqrt(D / 6.0), 0.1])
+
+        def krow_fn(i, X):
+            r = np.sqrt(((X[i] - X) ** 2).sum(1)) / th[1]
+            return th[0] * (1 + math.sqrt(5) * r + r * r) * np.exp(-math.sqrt(5) * r)  # kernel.go:89-92
+    else:
+        N, D = 65536, 32
+        simil = kernel.Scaled(kernel.ARD(kernel.Normal, D))
+        ls = math.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D))  # SURVEY 8d
+        th = np.concatenate([[1.0], ls, [0.1]])
+
+        def krow_fn(i, X):
+            return th[0] * np.exp(-0.5 * (((X[i] - X) / ls) ** 2).sum(1))
+    X, y = synth.make_inputs(N, D, 20251114 + (3 if shape == "config4" else 4))
+    g = gpmod.GP(D, simil, kernel.UniformNoise, X=X, Y=y)
+    x = np.log(th)
+    s2 = th[-1] ** 2
+    lml = g.Observe(x)
+    grad = g.Gradient()
+    assert np.isfinite(lml) and grad.shape == x.shape
+    alpha = g.Alpha
+    rng = np.random.default_rng(2)
+    for i in rng.integers(0, N, 8):
+        krow = krow_fn(i, X)
+        krow[i] += s2
+        assert abs(krow @ alpha - y[i]) <= 1e-8 * max(1.0, np.abs(krow * alpha).sum()), i
+    v = rng.normal(size=len(x))
+    v /= np.linalg.norm(v)
+    h = 1e-4
+    fd = (g.Observe(x + h * v) - g.Observe(x - h * v)) / (2 * h)
+    assert abs(fd - grad @ v) <= 1e-6 * max(1.0, abs(fd)), (fd, grad @ v)
+    g.Observe(x)
+    idx = rng.integers(0, N, 1024)
+    mu, sigma = g.Produce(X[idx])
+    np.testing.assert_allclose(mu, (y - s2 * alpha)[idx], rtol=0, atol=1e-8 * max(1.0, np.abs(y).max()))
+    assert np.all(np.isfinite(sigma)) and np.all(sigma < th[-1] * 1.0001)  # latent sd at a training input < noise sd
+    g.close()
+
+
 def test_handle_reuse_across_sizes_and_call_orders(gpmod):
     """One GP value reused with growing and shrinking data, every call order the API
     allows (Observe -> Gradient twice, Observe -> Observe, Observe -> Absorb -> Produce,
