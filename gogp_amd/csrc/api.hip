@@ -71,6 +71,11 @@ struct gogp_handle {
   int64_t lauum_ksplit = 0;  // columns already summed by the early part (this evaluation)
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
+  hipStream_t sv = nullptr;  // the chain server (resident diagonal-block workgroup)
+  unsigned *chain_flags = nullptr;  // [in: CHAIN_MAX_PANELS | out: CHAIN_MAX_PANELS | err]
+  unsigned chain_epoch = 0;
+  int chain_server = 0;        // diagonal blocks by the resident server instead of one launch each
+                               // (measured: removes the placement waits, no end-to-end gain; option)
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
   int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
@@ -189,11 +194,12 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) {
+  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sv}) {
     if (q) (void)hipStreamSynchronize(q);
     if (q) (void)hipStreamDestroy(q);
   }
   if (h->s) (void)hipStreamDestroy(h->s);
+  (void)hipFree(h->chain_flags);
   delete h;
 }
 
@@ -257,7 +263,10 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
     e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->sl, hipStreamNonBlocking, least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->sv, hipStreamNonBlocking, greatest);
   }
+  if (e == hipSuccess) e = hipMalloc(&h->chain_flags, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(h->chain_flags, 0, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
@@ -459,6 +468,19 @@ static int factorize(gogp_handle *h, bool eager) {
   if (eager && !h->bufY)
     HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
+  const int npanel_all = (int)(npad / PANEL);
+  // The chain server goes out first, while the GPU has an empty CU for it; it reads
+  // *info's zero and the Gram matrix only after flag 0 is raised behind both.
+  const bool server = h->chain_server && npanel_all <= CHAIN_MAX_PANELS;
+  unsigned *flag_in = h->chain_flags, *flag_out = h->chain_flags + CHAIN_MAX_PANELS;
+  unsigned *flag_err = h->chain_flags + 2 * CHAIN_MAX_PANELS;
+  unsigned epoch = 0;
+  if (server) {
+    epoch = ++h->chain_epoch;
+    if (epoch == 0) epoch = ++h->chain_epoch;  // 0 is the cleared state
+    launch_diag256_server(h->sv, h->bufA, ld, h->bufL, ld, h->Dinv, npanel_all, h->n, h->info,
+                          flag_in, flag_out, flag_err, epoch);
+  }
   launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
   order(h, EV_GRAM, s, sp);
   if (eager) {
@@ -487,7 +509,12 @@ static int factorize(gogp_handle *h, bool eager) {
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
       double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
       // 256x256 diagonal block: factor + dense inverse, one workgroup
-      launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+      if (server) {
+        launch_chain_flag_set(sp, flag_in + p, epoch);            // block p has its last update
+        launch_chain_flag_wait(sp, flag_out + p, epoch, flag_err);  // ... and is factored
+      } else {
+        launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+      }
       const int mt2 = (int)((npad - c2) / TILE);
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
       if (mt2 > 0)
@@ -549,6 +576,8 @@ static int factorize(gogp_handle *h, bool eager) {
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
+  if (server)
+    HIPCHK(h, hipMemcpyAsync(h->hscal + 9, flag_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
     // triangular inverse is complete (st), instead of 64 dependent substitution steps
@@ -566,6 +595,18 @@ static int factorize(gogp_handle *h, bool eager) {
   h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  if (server) {
+    unsigned cerr = 0;
+    memcpy(&cerr, h->hscal + 9, sizeof cerr);
+    if (cerr != 0) {  // a spin limit expired: the chain drained without doing its work
+      for (hipStream_t q : {sp, st, s2, h->sl, h->sv}) (void)hipStreamSynchronize(q);
+      (void)hipMemset(flag_err, 0, sizeof(unsigned));
+      h->alpha_pending = false;
+      h->trtri_done = h->trtri_pending = false;
+      h->lauum_ksplit = 0;
+      return fail(h, GOGP_EHIP, "chain server: a flag wait timed out");
+    }
+  }
   long long info = 0;
   memcpy(&info, h->hscal + 8, sizeof info);
   if (info != 0) {
@@ -1227,6 +1268,10 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "lauum_split") == 0) {
     if (value < 0 || value > 95) return fail(h, GOGP_EARG, "lauum_split must be 0..95 (percent)");
     h->lauum_split_pct = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "chain_server") == 0) {
+    h->chain_server = value != 0;
     return GOGP_OK;
   }
   if (strcmp(name, "superpanel") == 0) {

@@ -99,6 +99,15 @@ void launch_diag128_inv_only(hipStream_t s, const double *L, int64_t ld, double 
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
+// chain server (diag256.hip): one resident workgroup factors the diagonal blocks 0..npanel-1
+// in order, driven by epoch-valued flags; set / wait are the stream-side ends of the flags
+void launch_diag256_server(hipStream_t s, const double *A, int64_t ld, double *L, int64_t ldl,
+                           double *Dinv, int npanel, int64_t nvalid, long long *info,
+                           const unsigned *flag_in, unsigned *flag_out, unsigned *err,
+                           unsigned epoch);
+void launch_chain_flag_set(hipStream_t s, unsigned *flag, unsigned epoch);
+void launch_chain_flag_wait(hipStream_t s, const unsigned *flag, unsigned epoch, unsigned *err);
+constexpr int CHAIN_MAX_PANELS = 4096;  // N up to 1M
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld);
 void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,

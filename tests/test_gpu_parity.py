@@ -441,6 +441,30 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
     g.close()
 
 
+def test_chain_server_option_same_results(gpmod):
+    """The resident chain server (one persistent workgroup factoring the diagonal blocks,
+    flag-driven) gives bit-identical results to one launch per block."""
+    rng = np.random.default_rng(5)
+    n, D = 1800, 3
+    X, y = _data(rng, n, D)
+    x = np.log([1.1, 0.5, 0.2])
+    out = []
+    for mode in (0, 1, 1):
+        g = gpmod.GP(D, kernel.Scaled(kernel.Matern32), kernel.UniformNoise, X=X, Y=y)
+        g.set_option("chain_server", mode)
+        lml = g.Observe(x)
+        grad = g.Gradient()
+        lml2 = g.Observe(x + 0.01)  # second factorisation on the same handle: next epoch
+        mu, sigma = g.Produce(X[:7])
+        out.append((lml, grad, lml2, mu, sigma))
+        g.close()
+    for o in out[1:]:
+        assert o[0] == out[0][0] and o[2] == out[0][2]
+        np.testing.assert_array_equal(o[1], out[0][1])
+        np.testing.assert_array_equal(o[3], out[0][3])
+        np.testing.assert_array_equal(o[4], out[0][4])
+
+
 def test_handle_reuse_across_sizes_and_call_orders(gpmod):
     """One GP value reused with growing and shrinking data, every call order the API
     allows (Observe -> Gradient twice, Observe -> Observe, Observe -> Absorb -> Produce,
