@@ -73,15 +73,6 @@ void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, 
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
                   double *prior);
 
-// potrf + inverse of one 128x128 diagonal block.
-//   A (ld): in: lower triangle of the block; Lout (ldl): out: lower factor
-//   (upper zeroed); Dinv: out: dense 128x128 inverse of the factor (upper zero).
-//   info: device int64; set to (row0+j+1) at the first non-positive pivot with
-//   row0+j < nvalid (atomicMin-like: first failure wins).
-void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout,
-                    int64_t ldl, double *Dinv, int64_t row0, int64_t nvalid,
-                    long long *info);
-
 // forward / backward substitution steps with the stored 256x256 block inverses
 // (b, nb count 256-blocks)
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
@@ -93,9 +84,11 @@ void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const doub
 // (i < n; the last only when alpha != nullptr)
 void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars);
-void launch_diag128_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
 // potrf + dense inverse of one 256x256 diagonal block (diag256.hip); Dinv has
-// leading dimension 256.
+// leading dimension 256.  A (ld): in: lower triangle of the block; Lout (ldl): out: lower
+// factor (upper zeroed); Dinv: out: dense inverse of the factor (upper zero).  info: device
+// int64, set to (row0+j+1) at the first non-positive pivot with row0+j < nvalid (first
+// failure wins).
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
