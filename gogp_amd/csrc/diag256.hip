@@ -50,47 +50,66 @@ __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// 16x16 Cholesky by ONE wave: lanes 0..15 own row r of the block (lanes 16..63
-// mirror them), right-looking with v_readlane broadcasts; 1/sqrt by v_rsq_f64 +
-// two Newton steps.  Writes the factor (upper zeroed) back to S and 1/L_jj to
-// rinv[0..15] (LDS).
-__device__ __forceinline__ void potrf16(double *S, int kb, volatile double *rinv, int lane,
-                                        long grow0, long nvalid, long long *info) {
+// Column block kb of the 128x128 matrix in S, factored AND solved by one wave in one pass:
+// lanes 0..15 own row r of the 16x16 diagonal block (right-looking Cholesky with
+// v_readlane broadcasts; 1/sqrt by v_rsq_f64 + two Newton steps), lanes 16..63 own 48 of
+// the rows below it (row0 + lane - 16, rows >= 128 idle) and execute the SAME instructions:
+// scaling by 1/L_jj and the rank-1 update with the broadcast pivot-row values is exactly the
+// forward substitution of their row against the block, so the panel solve costs nothing on
+// top of the factorisation.  Waves that only carry panel rows redo the diagonal block
+// redundantly (write_diag = false).  Writes the factor block (upper zeroed), 1/L_jj to
+// rinv[0..15] (LDS) and the solved rows back to S; the columns form one basic block (the
+// not-positive-definite test is branch-free and reported once at the end).
+__device__ __forceinline__ void panel16(double *S, int kb, double *rinv, int lane, int row0,
+                                        bool write_diag, long grow0, long nvalid,
+                                        long long *info) {
   const int r = lane & 15;
+  const bool prow = lane >= 16;                      // panel-row lane
+  const int row = prow ? row0 + lane - 16 : kb * 16 + r;
+  const bool live = row < 128;
   double a[16];
-  double *src = S + (kb * 16 + r) * SLD + kb * 16;
+  double *src = S + (live ? row : 127) * SLD + kb * 16;
 #pragma unroll
   for (int c = 0; c < 16; ++c) a[c] = src[c];
+  double mine = 0.0;
+  int bad = 16;  // first non-positive pivot
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    double d = readlane_d(a[j], j);
-    if (!(d > 0.0)) {
-      if (lane == 0 && grow0 + j < nvalid && *info == 0) *info = (long long)(grow0 + j + 1);
-      d = 1.0;
-    }
+    const double d = readlane_d(a[j], j);
+    // off the dependency chain: a non-positive (or NaN) pivot is only recorded; its rsq is
+    // NaN/inf and poisons the rest of the factor, which the caller discards (GOGP_ENOTPD)
+    bad = (!(d > 0.0) && bad == 16) ? j : bad;
     double rs = __builtin_amdgcn_rsq(d);
 #ifndef GOGP_RSQ_NEWTON
 #define GOGP_RSQ_NEWTON 2
 #endif
 #pragma unroll
     for (int it = 0; it < GOGP_RSQ_NEWTON; ++it) rs = fma(rs * 0.5, fma(-d * rs, rs, 1.0), rs);
-    if (lane == 0) rinv[j] = rs;
-    const double lrj = a[j] * rs;  // lane j: d/sqrt(d) = sqrt(d)
+    mine = (lane == j) ? rs : mine;  // lane j keeps 1/L_jj; stored once below
+    const double lrj = a[j] * rs;    // lane j: d/sqrt(d) = sqrt(d)
     a[j] = lrj;
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] -= lrj * readlane_d(lrj, c);
   }
-  if (lane < 16) {
+  if (prow) {
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) src[c] = a[c];
+    }
+  } else if (write_diag) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) src[c] = (c <= r) ? a[c] : 0.0;
+    rinv[r] = mine;
   }
+  if (write_diag && bad < 16 && lane == 0 && grow0 + bad < nvalid && *info == 0)
+    *info = (long long)(grow0 + bad + 1);
 }
 
 // Inverse of the 16x16 lower-triangular diagonal block kb of S by ONE wave (lane c
 // owns column c, forward substitution with v_readlane broadcasts of the rows).
 // HAVE_RINV: 1/L_jj is already in rinv[]; otherwise it is formed here.
 template <bool HAVE_RINV>
-__device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, volatile double *rinv,
+__device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, const double *rinv,
                                       int lane) {
   const int r = lane & 15;
   double a[16];
@@ -121,74 +140,53 @@ __device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, volat
 }
 
 // In-LDS blocked Cholesky of the 128x128 matrix in S (lower triangle valid, upper
-// zero), block size 16, with in-kernel look-ahead:
-//   panel solve  : every row below the diagonal block is solved by ONE lane
-//                  (forward substitution against the 16x16 factor, broadcast LDS reads);
-//   trailing     : MFMA rank-16 updates; wave 0 updates the next diagonal tile first
-//                  and factors it while waves 1..7 update the other tiles.
+// zero), block size 16.  Per step kb -> kb+1:
+//   A. the eight waves update column block kb+1 by panel kb (one 16x16 tile each, MFMA);
+//   B. waves 0..2 factor + solve column block kb+1 (panel16: the diagonal block and up to
+//      3 x 48 rows below, one pass), while waves 3..7 apply panel kb to the rest of the
+//      trailing matrix (MFMA rank-16 updates) -- off the critical path.
+// The critical path per step is one tile update + one panel16 + two barriers.
 // On exit S = L (upper zero) and XD[kb] = inverse of L's kb-th diagonal block (the
 // eight inverses are formed at the end by eight waves in parallel).
+__device__ __forceinline__ void tile_update16(double *S, int i, int c, int kb, int fr, int fk) {
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const double av = S[(i * 16 + fr) * SLD + kb * 16 + k4 * 4 + fk];
+    const double bv = S[(c * 16 + fr) * SLD + kb * 16 + k4 * 4 + fk];
+    acc = mfma(av, bv, acc);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) S[(i * 16 + fk + 4 * v) * SLD + c * 16 + fr] -= acc[v];
+}
+
 __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long grow0,
                              long nvalid, long long *info, unsigned long long *st = nullptr) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  if (w == 0) potrf16(S, 0, rinv, lane, grow0, nvalid, info);
+  // rows below block kb: (7-kb)*16; wave w < 3 carries rows (kb+1)*16 + 48w .. +47
+  if (w < 3) panel16(S, 0, rinv, lane, 16 + 48 * w, w == 0, grow0, nvalid, info);
+  if (st && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
   __syncthreads();
-  for (int kb = 0; kb < 8; ++kb) {
-    // ---- panel solve: rows (kb+1)*16 .. 127, one lane per row -----------------------
-    {
-      const int row = (kb + 1) * 16 + tid;
-      if (row < 128) {
-        double *ap = S + row * SLD + kb * 16;
-        const double *Lb = S + (kb * 16) * SLD + kb * 16;
-        const double *ri = rinv + kb * 16;
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = ap[c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          // row c of the 16x16 factor: broadcast LDS reads issued together, consumed at
-          // once; the fence keeps hipcc from hoisting all 120 reads (register spills)
-          double lr[16];
-#pragma unroll
-          for (int q = 0; q < c; ++q) lr[q] = Lb[c * SLD + q];
-          double t = x[c];
-#pragma unroll
-          for (int q = 0; q < c; ++q) t -= x[q] * lr[q];
-          x[c] = t * ri[c];
-          asm volatile("" ::: "memory");
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) ap[c] = x[c];
-      }
-    }
-    if (st && tid == 0 && kb < 2) st[kb * 3 + 1] = __builtin_amdgcn_s_memtime();
+  for (int kb = 0; kb < 7; ++kb) {
+    // ---- A: column block kb+1: tiles (i, kb+1), i = kb+1 .. 7 ---------------------------
+    if (kb + 1 + w < 8) tile_update16(S, kb + 1 + w, kb + 1, kb, fr, fk);
     __syncthreads();
-    if (kb == 7) break;
-    // ---- trailing update A[i,c] -= L[i,kb] L[c,kb]^T for kb < c <= i ---------------------
-    {
-      const int m = 7 - kb;
+    // ---- B -------------------------------------------------------------------------------
+    if (w < 3) {
+      if ((kb + 2) * 16 + 48 * w < 128 || w == 0)
+        panel16(S, kb + 1, rinv + (kb + 1) * 16, lane, (kb + 2) * 16 + 48 * w, w == 0,
+                grow0 + (kb + 1) * 16, nvalid, info);
+      if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
+    } else {
+      // tiles (i, c), kb+2 <= c <= i <= 7, dealt to waves 3..7
+      const int m = 6 - kb;  // block columns kb+2 .. 7
       const int nt3 = m * (m + 1) / 2;
-      // wave 0: tile 0 = (kb+1, kb+1), then the next 16x16 factorisation;
-      // waves 1..7: tiles 1 .. nt3-1
-      for (int t = (w == 0 ? 0 : w); t < (w == 0 ? 1 : nt3); t += 7) {
+      for (int t = w - 3; t < nt3; t += 5) {
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
         const int cc = t - ii * (ii + 1) / 2;
-        const int i = kb + 1 + ii, c = kb + 1 + cc;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const double av = S[(i * 16 + fr) * SLD + kb * 16 + k4 * 4 + fk];
-          const double bv = S[(c * 16 + fr) * SLD + kb * 16 + k4 * 4 + fk];
-          acc = mfma(av, bv, acc);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) S[(i * 16 + fk + 4 * v) * SLD + c * 16 + fr] -= acc[v];
-      }
-      if (w == 0) {
-        potrf16(S, kb + 1, rinv + (kb + 1) * 16, lane, grow0 + (kb + 1) * 16, nvalid, info);
-        if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
+        tile_update16(S, kb + 2 + ii, kb + 2 + cc, kb, fr, fk);
       }
     }
     __syncthreads();
@@ -275,13 +273,21 @@ __device__ void invert128_lds(double *S, const double *XD, int tid) {
 }
 
 // C (128x128; wave (wr,wc) of a 4x2 arrangement owns rows wr*32.., cols wc*64..:
-// 2x4 MFMA tiles) = A * B with A = S (LDS, row-major [i][k]) and the B fragments
-// loaded straight from global memory (L2-resident, written earlier by this
-// workgroup) one 16-k chunk ahead: no staging buffer and no barrier inside.
+// 2x4 MFMA tiles) = A * B with A = S (LDS, row-major [i][k]) and B from global memory
+// (L2-resident: written earlier by this workgroup or by the panel update), staged
+// through LDS in 8-deep k chunks, double-buffered in G (free during these phases): every
+// B element is fetched ONCE per workgroup, a whole chunk ahead of its use; one barrier per
+// chunk.  (The earlier form loaded B fragments straight into registers, 4x redundantly
+// across the waves and one chunk of latency exposed: 45-57K cycles per product.)
 //   B_NT: B[k][j] = Bg[j*ldb + k]   (rows of Bg are the columns of B)
+//         chunk layout Bs[j][9]   : fragment reads hit distinct 8-B banks but one pair
 //   else: B[k][j] = Bg[k*ldb + j]
+//         chunk layout Bs[k][144] : conflict-free (stride = 16 mod 32 banks)
+constexpr int BCH = 8;            // k per chunk
+constexpr int BBUF = 1152;        // doubles per chunk buffer (128*9 = 8*144); 2 buffers = GSIZE
+static_assert(2 * BBUF <= GSIZE, "chunk buffers must fit G");
 template <bool B_NT>
-__device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, const double *Bg, long ldb,
+__device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const double *Bg, long ldb,
                            int tid) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -290,54 +296,54 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, const double *Bg, 
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) c[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  // The k index inside an MFMA step is arbitrary as long as A and B agree.
-  //   NN: lane group fk supplies k = 4*s + fk in step s (rows of Bg are k: the 16
-  //       lanes of a group read 128 contiguous bytes);
-  //   NT: lane group fk supplies k = 4*fk + s in step s, so that a lane's four k of
-  //       a 16-k chunk are 32 contiguous bytes of ITS row of Bg (two 16-B loads per
-  //       chunk, the four groups cover the row's whole 128-B line).
-  const double *pn[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n)
-    pn[n] = B_NT ? Bg + (long)(wc * 64 + n * 16 + fr) * ldb + 4 * fk
-                 : Bg + (long)fk * ldb + wc * 64 + n * 16 + fr;
-  const double *ap = S + (wr * 32 + fr) * SLD + (B_NT ? 4 * fk : fk);
-  constexpr int ASTEP = B_NT ? 1 : 4;  // A column advance per k4 step inside a chunk
-  double bA[4][4], bB[4][4];
-#define GOGP_LOADB(dst)                                                              \
-  if (B_NT) {                                                                        \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                  \
-      const double2 v0 = *reinterpret_cast<const double2 *>(pn[n]);                  \
-      const double2 v1 = *reinterpret_cast<const double2 *>(pn[n] + 2);              \
-      dst[0][n] = v0.x; dst[1][n] = v0.y; dst[2][n] = v1.x; dst[3][n] = v1.y;        \
-      pn[n] += 16;                                                                   \
-    }                                                                                \
-  } else {                                                                           \
-    _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                               \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n) dst[k4][n] = pn[n][0];           \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n) pn[n] += 4 * ldb;                \
-    }                                                                                \
+  // staging map: 512 threads x 16 B = one 8 x 128 chunk
+  const double *gp;   // this thread's 16 B of chunk 0
+  long gstep;         // advance per chunk
+  int so;             // LDS offset of its first double
+  if (B_NT) {
+    const int jj = tid >> 2, kq = (tid & 3) * 2;
+    gp = Bg + (long)jj * ldb + kq;
+    gstep = BCH;
+    so = jj * 9 + kq;
+  } else {
+    const int kk = tid >> 6, j2 = (tid & 63) * 2;
+    gp = Bg + (long)kk * ldb + j2;
+    gstep = BCH * ldb;
+    so = kk * 144 + j2;
   }
-#define GOGP_CHUNK(cur, kc)                                                          \
-  _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                                 \
-    const double a0 = ap[(kc) * 16 + k4 * ASTEP];                                    \
-    const double a1 = ap[16 * SLD + (kc) * 16 + k4 * ASTEP];                         \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                  \
-      c[0][n] = mfma(a0, cur[k4][n], c[0][n]);                                       \
-      c[1][n] = mfma(a1, cur[k4][n], c[1][n]);                                       \
-    }                                                                                \
-  }
-  GOGP_LOADB(bA)
+  const double *ap = S + (wr * 32 + fr) * SLD + fk;
+  const int bo = B_NT ? (wc * 64 + fr) * 9 + fk : fk * 144 + wc * 64 + fr;
+  constexpr int BN = B_NT ? 16 * 9 : 16;   // fragment offset per n tile
+  constexpr int BS = B_NT ? 4 : 4 * 144;   // ... per k4 step
+  double2 pre = *reinterpret_cast<const double2 *>(gp);
+  G[so] = pre.x;
+  G[so + 1] = pre.y;
+  __syncthreads();
 #pragma unroll 1
-  for (int kc = 0; kc < 8; kc += 2) {
-    GOGP_LOADB(bB)  // chunk kc+1 in flight while chunk kc computes
-    GOGP_CHUNK(bA, kc)
-    if (kc + 2 < 8) { GOGP_LOADB(bA) }
-    GOGP_CHUNK(bB, kc + 1)
+  for (int kc = 0; kc < 128 / BCH; ++kc) {
+    const bool more = kc + 1 < 128 / BCH;
+    if (more) pre = *reinterpret_cast<const double2 *>(gp + (long)(kc + 1) * gstep);
+    const double *bs = G + (kc & 1) * BBUF + bo;
+#pragma unroll
+    for (int k4 = 0; k4 < BCH / 4; ++k4) {
+      const double a0 = ap[kc * BCH + k4 * 4];
+      const double a1 = ap[16 * SLD + kc * BCH + k4 * 4];
+      double b[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = bs[n * BN + k4 * BS];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        c[0][n] = mfma(a0, b[n], c[0][n]);
+        c[1][n] = mfma(a1, b[n], c[1][n]);
+      }
+    }
+    if (more) {
+      double *d = G + ((kc + 1) & 1) * BBUF + so;
+      d[0] = pre.x;
+      d[1] = pre.y;
+    }
+    __syncthreads();  // chunk kc+1 visible; everybody done with chunk kc (and, at the end, with S)
   }
-#undef GOGP_CHUNK
-#undef GOGP_LOADB
-  __syncthreads();  // every wave is done reading S
 }
 
 }  // namespace
@@ -384,7 +390,7 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
       __syncthreads();
     } else {
       // S currently holds L10 (row-major): C = L10 * L10^T
-      wg_gemm128<true>(c, S, L10g, ld10, tid);
+      wg_gemm128<true>(c, S, G, L10g, ld10, tid);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -426,7 +432,7 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
     if (half == 0) {
       // ---- L10 = A10 X00^T, computed as C = X00 * A10^T = L10^T ------------------------
       if (DO_POTRF) {
-        wg_gemm128<true>(c, S, A + 128 * ld, ld, tid);
+        wg_gemm128<true>(c, S, G, A + 128 * ld, ld, tid);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -452,7 +458,7 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
   }
   // ---- X10 = -X11 L10 X00 : S = X11 now ------------------------------------------------
   GOGP_STAMP(16);
-  wg_gemm128<false>(c, S, L10g, ld10, tid);  // U = X11 * L10
+  wg_gemm128<false>(c, S, G, L10g, ld10, tid);  // U = X11 * L10
   GOGP_STAMP(17);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -462,7 +468,7 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
       for (int v = 0; v < 4; ++v)
         S[(wr * 32 + m * 16 + fk + 4 * v) * SLD + wc * 64 + n * 16 + fr] = c[m][n][v];
   __syncthreads();
-  wg_gemm128<false>(c, S, Dinv, 256, tid);  // U * X00
+  wg_gemm128<false>(c, S, G, Dinv, 256, tid);  // U * X00
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -20,8 +20,8 @@ for k in sorted(names):
     print("%-22s +%7d cyc  (total %7d)" % (names[k], t - prev, t - t0))
     prev = t
 
-t1 = int(st[1])
-for kb in range(2):
-    a, b, c = int(st[19 + kb * 3]), int(st[20 + kb * 3]), int(st[21 + kb * 3])
-    print("kb=%d: base16 done +%d, P2 done +%d, P3 done +%d" % (kb, a - t1, b - a, c - b))
-    t1 = c
+# sub-stamps of potrf128 (half 0): st[20] = solve kb=0 done, st[21] = wave 0's update + potrf16(1)
+# done, st[23] = solve kb=1 done, st[24] = potrf16(2) done
+t1, s0, p1, s1, p2 = int(st[1]), int(st[20]), int(st[21]), int(st[21]), int(st[24])
+print("potrf16(0)+solve(0): %d | update+potrf16(1): %d | barrier+solve(1): %d | update+potrf16(2): %d" % (
+    s0 - t1, p1 - s0, s1 - p1, p2 - s1))
