@@ -30,6 +30,7 @@
 namespace gogp {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -198,6 +199,71 @@ __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long 
 
 // S holds a lower-triangular L (128x128) whose eight 16x16 diagonal-block
 // inverses are in XD: overwrite S with X = L^-1 by recursive doubling.
+// One product phase of invert128_lds: this wave's (up to) two 16x16 tiles of
+// C = A_blk * B_blk, A_blk at (ra, ca), B_blk at (ca, cb) relative to the pair origin.
+// All fragments of both tiles are requested first (BS/4 k steps each), then the two
+// accumulator chains are interleaved: the LDS latency is paid once per phase instead of
+// once per k step, and consecutive MFMAs are independent.
+template <int BS>
+__device__ __forceinline__ void inv_phase(const double *S, f64x4 (&acc)[2], int w, int fr, int fk,
+                                          int aoff, int boff) {
+  constexpr int TB = BS / 16, NTPP = TB * TB, NTL = 4 * TB, KS = BS / 4;
+  double av[2][KS], bv[2][KS];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tile = w + u * NW;
+    acc[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    if (tile < NTL) {
+      const int p = tile / NTPP, tl = tile - p * NTPP;
+      const int ti = tl / TB, tj = tl - ti * TB, o = p * 2 * BS;
+      // A_blk row block ti: rows o + BS + ti*16 + fr, columns o + aoff + k
+      // B_blk column block tj: rows o + boff + k, columns o + tj*16 + fr
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        av[u][ks] = S[(o + BS + ti * 16 + fr) * SLD + o + aoff + ks * 4 + fk];
+        bv[u][ks] = S[(o + boff + ks * 4 + fk) * SLD + o + tj * 16 + fr];
+      }
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (w + u * NW < NTL) acc[u] = mfma(av[u][ks], bv[u][ks], acc[u]);
+}
+
+template <int BS>
+__device__ __forceinline__ void inv_store(double *S, const f64x4 (&acc)[2], int w, int fr, int fk,
+                                          double sign) {
+  constexpr int TB = BS / 16, NTPP = TB * TB, NTL = 4 * TB;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tile = w + u * NW;
+    if (tile < NTL) {
+      const int p = tile / NTPP, tl = tile - p * NTPP;
+      const int ti = tl / TB, tj = tl - ti * TB, o = p * 2 * BS;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        S[(o + BS + ti * 16 + fk + 4 * v) * SLD + o + tj * 16 + fr] = sign * acc[u][v];
+    }
+  }
+}
+
+template <int BS>
+__device__ __forceinline__ void inv_level(double *S, int w, int fr, int fk) {
+  f64x4 acc[2];
+  // T = B * Xa   (B at (o+BS, o), Xa at (o, o)): A_blk columns o + 0.., B_blk rows o + 0..
+  inv_phase<BS>(S, acc, w, fr, fk, 0, 0);
+  __syncthreads();
+  inv_store<BS>(S, acc, w, fr, fk, 1.0);
+  __syncthreads();
+  // Z = -Xc * T  (Xc at (o+BS, o+BS)): A_blk columns o + BS.., B_blk rows o + BS..
+  inv_phase<BS>(S, acc, w, fr, fk, BS, BS);
+  __syncthreads();
+  inv_store<BS>(S, acc, w, fr, fk, -1.0);
+  __syncthreads();
+}
+
 __device__ void invert128_lds(double *S, const double *XD, int tid) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -207,86 +273,37 @@ __device__ void invert128_lds(double *S, const double *XD, int tid) {
     S[(kb * 16 + rr) * SLD + kb * 16 + c] = XD[kb * 16 * XLD + rr * XLD + c];
   }
   __syncthreads();
-#pragma unroll
-  for (int bs = 16; bs <= 64; bs *= 2) {
-    const int tb = bs / 16;    // tiles per block side
-    const int ntpp = tb * tb;  // tiles per pair
-    const int ntl = 4 * tb;    // tiles of this level: (64/bs) pairs * ntpp  (4, 8, 16)
-    f64x4 acc[2];
-    // T = B * Xa   (B at (o+bs, o), Xa at (o, o))
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int tile = w + u * NW;
-      acc[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
-      if (tile < ntl) {
-        const int p = tile / ntpp, tl = tile - p * ntpp;
-        const int ti = tl / tb, tj = tl - ti * tb, o = p * 2 * bs;
-        for (int k0 = 0; k0 < bs; k0 += 4) {
-          const double av = S[(o + bs + ti * 16 + fr) * SLD + o + k0 + fk];
-          const double bv = S[(o + k0 + fk) * SLD + o + tj * 16 + fr];
-          acc[u] = mfma(av, bv, acc[u]);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int tile = w + u * NW;
-      if (tile < ntl) {
-        const int p = tile / ntpp, tl = tile - p * ntpp;
-        const int ti = tl / tb, tj = tl - ti * tb, o = p * 2 * bs;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          S[(o + bs + ti * 16 + fk + 4 * v) * SLD + o + tj * 16 + fr] = acc[u][v];
-      }
-    }
-    __syncthreads();
-    // Z = -Xc * T  (Xc at (o+bs, o+bs))
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int tile = w + u * NW;
-      acc[u] = (f64x4){0.0, 0.0, 0.0, 0.0};
-      if (tile < ntl) {
-        const int p = tile / ntpp, tl = tile - p * ntpp;
-        const int ti = tl / tb, tj = tl - ti * tb, o = p * 2 * bs;
-        for (int k0 = 0; k0 < bs; k0 += 4) {
-          const double av = S[(o + bs + ti * 16 + fr) * SLD + o + bs + k0 + fk];
-          const double bv = S[(o + bs + k0 + fk) * SLD + o + tj * 16 + fr];
-          acc[u] = mfma(av, bv, acc[u]);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int tile = w + u * NW;
-      if (tile < ntl) {
-        const int p = tile / ntpp, tl = tile - p * ntpp;
-        const int ti = tl / tb, tj = tl - ti * tb, o = p * 2 * bs;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          S[(o + bs + ti * 16 + fk + 4 * v) * SLD + o + tj * 16 + fr] = -acc[u][v];
-      }
-    }
-    __syncthreads();
-  }
+  inv_level<16>(S, w, fr, fk);
+  inv_level<32>(S, w, fr, fk);
+  inv_level<64>(S, w, fr, fk);
 }
 
-// C (128x128; wave (wr,wc) of a 4x2 arrangement owns rows wr*32.., cols wc*64..:
-// 2x4 MFMA tiles) = A * B with A = S (LDS, row-major [i][k]) and B from global memory
+// C (128x128) = A * B with A = S (LDS, row-major [i][k]) and B from global memory
 // (L2-resident: written earlier by this workgroup or by the panel update), staged
 // through LDS in 8-deep k chunks, double-buffered in G (free during these phases): every
 // B element is fetched ONCE per workgroup, a whole chunk ahead of its use; one barrier per
-// chunk.  (The earlier form loaded B fragments straight into registers, 4x redundantly
-// across the waves and one chunk of latency exposed: 45-57K cycles per product.)
+// chunk.
+//
+// Every product here has a triangular operand or a symmetric result, so half of the 16x16
+// block products are exact zeros (or not needed) and are skipped.  To keep the eight waves
+// equally loaded, wave (wr, wc) of the 4x2 arrangement owns the 16-row tiles
+// GOGP_RT(0) = wr and GOGP_RT(1) = 7 - wr and the 16-column tiles GOGP_CT(n) = 2n + wc:
+//   TRI_A   : A lower triangular  -> row tile rt only needs k < 16 (rt + 1)
+//   TRI_B   : B lower triangular  -> column tile ct only needs k >= 16 ct
+//   TRI_SYM : C = A A^T, lower tiles only -> tile (rt, ct) needed iff ct <= rt
+// (skipped accumulators stay zero).  2 x 128^3 flop on one CU is >= 13.8 us at the MFMA
+// rate; this cuts each product to 56-62 % of that.
 //   B_NT: B[k][j] = Bg[j*ldb + k]   (rows of Bg are the columns of B)
 //         chunk layout Bs[j][9]   : fragment reads hit distinct 8-B banks but one pair
 //   else: B[k][j] = Bg[k*ldb + j]
 //         chunk layout Bs[k][144] : conflict-free (stride = 16 mod 32 banks)
+#define GOGP_RT(m) ((m) ? 7 - wr : wr)
+#define GOGP_CT(n) (2 * (n) + wc)
+enum { TRI_A = 0, TRI_B = 1, TRI_SYM = 2 };
 constexpr int BCH = 8;            // k per chunk
 constexpr int BBUF = 1152;        // doubles per chunk buffer (128*9 = 8*144); 2 buffers = GSIZE
 static_assert(2 * BBUF <= GSIZE, "chunk buffers must fit G");
-template <bool B_NT>
+template <bool B_NT, int TRI>
 __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const double *Bg, long ldb,
                            int tid) {
   const int lane = tid & 63, w = tid >> 6;
@@ -311,10 +328,36 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const d
     gstep = BCH * ldb;
     so = kk * 144 + j2;
   }
-  const double *ap = S + (wr * 32 + fr) * SLD + fk;
-  const int bo = B_NT ? (wc * 64 + fr) * 9 + fk : fk * 144 + wc * 64 + fr;
-  constexpr int BN = B_NT ? 16 * 9 : 16;   // fragment offset per n tile
+  const double *ap0 = S + (GOGP_RT(0) * 16 + fr) * SLD + fk;
+  const double *ap1 = S + (GOGP_RT(1) * 16 + fr) * SLD + fk;
+  const int bo = B_NT ? (wc * 16 + fr) * 9 + fk : fk * 144 + wc * 16 + fr;
+  constexpr int BN = B_NT ? 32 * 9 : 32;   // fragment offset per n (column tiles 2n + wc)
   constexpr int BS = B_NT ? 4 : 4 * 144;   // ... per k4 step
+  // wave-uniform work limits (in chunks / tiles)
+  const int e0 = (TRI == TRI_A) ? 2 * (GOGP_RT(0) + 1) : 128 / BCH;  // row tile 0 active for kc < e0
+  const int e1 = (TRI == TRI_A) ? 2 * (GOGP_RT(1) + 1) : 128 / BCH;
+  const int n0 = (TRI == TRI_SYM) ? (wr >= wc ? (wr - wc) / 2 + 1 : 0) : 4;  // tiles (rt0, ct(n)), n < n0
+  const int n1 = (TRI == TRI_SYM) ? (7 - wr - wc) / 2 + 1 : 4;
+  if (TRI == TRI_SYM) {
+    // C = A A^T with A = S: the B fragments are rows of S as well (B[k][j] = S[j][k]); nothing
+    // is staged and nothing synchronised until the end
+    const double *bp = S + (wc * 16 + fr) * SLD + fk;  // column tile ct(n): + n * 32 rows
+#pragma unroll 2
+    for (int k4 = 0; k4 < 32; ++k4) {
+      const double a0 = ap0[k4 * 4];
+      const double a1 = ap1[k4 * 4];
+      double b[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = bp[n * 32 * SLD + k4 * 4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < n0) c[0][n] = mfma(a0, b[n], c[0][n]);
+        if (n < n1) c[1][n] = mfma(a1, b[n], c[1][n]);
+      }
+    }
+    __syncthreads();  // every wave is done reading S
+    return;
+  }
   double2 pre = *reinterpret_cast<const double2 *>(gp);
   G[so] = pre.x;
   G[so + 1] = pre.y;
@@ -324,17 +367,27 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const d
     const bool more = kc + 1 < 128 / BCH;
     if (more) pre = *reinterpret_cast<const double2 *>(gp + (long)(kc + 1) * gstep);
     const double *bs = G + (kc & 1) * BBUF + bo;
+    // first active column tile (TRI_B: ct(n) needs kc >= 2 ct(n))
+    int nb = 0;
+    if (TRI == TRI_B) {
+      const int h = kc / 2 - wc;                 // 2n <= h
+      nb = h < 0 ? 0 : min(4, h / 2 + 1);        // column tiles n < nb are active
+    }
+    const bool act0 = kc < e0, act1 = kc < e1;
+    if (act0 || act1) {
 #pragma unroll
-    for (int k4 = 0; k4 < BCH / 4; ++k4) {
-      const double a0 = ap[kc * BCH + k4 * 4];
-      const double a1 = ap[16 * SLD + kc * BCH + k4 * 4];
-      double b[4];
+      for (int k4 = 0; k4 < BCH / 4; ++k4) {
+        const double a0 = ap0[kc * BCH + k4 * 4];
+        const double a1 = ap1[kc * BCH + k4 * 4];
+        double b[4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) b[n] = bs[n * BN + k4 * BS];
+        for (int n = 0; n < 4; ++n) b[n] = bs[n * BN + k4 * BS];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        c[0][n] = mfma(a0, b[n], c[0][n]);
-        c[1][n] = mfma(a1, b[n], c[1][n]);
+        for (int n = 0; n < 4; ++n) {
+          const bool on = (TRI == TRI_B) ? n < nb : true;
+          if (on && act0 && n < n0) c[0][n] = mfma(a0, b[n], c[0][n]);
+          if (on && act1 && n < n1) c[1][n] = mfma(a1, b[n], c[1][n]);
+        }
       }
     }
     if (more) {
@@ -381,25 +434,39 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
     if (half == 0 || !DO_POTRF) {
       // unconditional 16-B loads, then select: a conditional load compiles into a
       // serialised branch + load + vmcnt(0) per element
+#pragma unroll 2
       for (int idx = tid; idx < 128 * 64; idx += NT) {
         const int i = idx >> 6, cc = (idx & 63) * 2;
-        const double2 v = *reinterpret_cast<const double2 *>(A + (off + i) * ld + off + cc);
-        S[i * SLD + cc] = (cc <= i) ? v.x : 0.0;
-        S[i * SLD + cc + 1] = (cc + 1 <= i) ? v.y : 0.0;
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(A + (off + i) * ld + off + cc);
+        *reinterpret_cast<f64x2 *>(S + i * SLD + cc) =
+            (f64x2){(cc <= i) ? v.x : 0.0, (cc + 1 <= i) ? v.y : 0.0};
       }
       __syncthreads();
     } else {
-      // S currently holds L10 (row-major): C = L10 * L10^T
-      wg_gemm128<true>(c, S, G, L10g, ld10, tid);
+      // S currently holds L10 (row-major): C = L10 * L10^T, lower tiles only (the
+      // accumulators of the tiles above the diagonal stay zero and are masked below)
+      wg_gemm128<true, TRI_SYM>(c, S, G, L10g, ld10, tid);
+      GOGP_STAMP(26);
+      // all 32 A11 requests of a lane go out together (one loop), the LDS stores follow in
+      // a second loop: fused, hipcc emits load / vmcnt(0) / store per element (~600 cycles
+      // each)
+      double a11[2][4][4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            a11[m][n][v] = A[(128 + GOGP_RT(m) * 16 + fk + 4 * v) * ld + 128 + GOGP_CT(n) * 16 + fr];
+      asm volatile("" ::: "memory");  // keep the two loops apart
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int i = wr * 32 + m * 16 + fk + 4 * v, cc = wc * 64 + n * 16 + fr;
-            const double a11 = A[(128 + i) * ld + 128 + cc];  // unconditional load, then select
-            S[i * SLD + cc] = (cc <= i) ? a11 - c[m][n][v] : 0.0;
+            const int i = GOGP_RT(m) * 16 + fk + 4 * v, cc = GOGP_CT(n) * 16 + fr;
+            S[i * SLD + cc] = (cc <= i) ? a11[m][n][v] - c[m][n][v] : 0.0;
           }
       __syncthreads();
     }
@@ -409,10 +476,14 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
       potrf128_lds(S, G, rinv_s, tid, row0 + off, nvalid, info,
                    (STAMP && half == 0) ? stamps + 19 : nullptr);
       GOGP_STAMP(half * 8 + 2);
-      for (int idx = tid; idx < 128 * 128; idx += NT) {
-        const int i = idx >> 7, cc = idx & 127;
-        Lout[(off + i) * ldl + off + cc] = S[i * SLD + cc];
-        if (half == 0) Lout[i * ldl + 128 + cc] = 0.0;  // upper-right block of the factor
+      // 16-B LDS reads / global stores (S rows are 1040 B apart: 16-B aligned)
+#pragma unroll 2
+      for (int idx = tid; idx < 128 * 64; idx += NT) {
+        const int i = idx >> 6, cc = (idx & 63) * 2;
+        *reinterpret_cast<f64x2 *>(Lout + (off + i) * ldl + off + cc) =
+            *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+        if (half == 0)  // upper-right block of the factor
+          *reinterpret_cast<f64x2 *>(Lout + i * ldl + 128 + cc) = (f64x2){0.0, 0.0};
       }
     } else {
       inv16<false>(S, w, G + w * 16 * XLD, rinv_s + w * 16, lane);
@@ -422,43 +493,45 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
     // ---- S <- inverse of the 128-block; write it out ----------------------------------
     invert128_lds(S, G, tid);
     GOGP_STAMP(half * 8 + 4);
-    for (int idx = tid; idx < 128 * 128; idx += NT) {
-      const int i = idx >> 7, cc = idx & 127;
-      Dinv[(off + i) * 256 + off + cc] = S[i * SLD + cc];
-      if (half == 0) Dinv[i * 256 + 128 + cc] = 0.0;
+#pragma unroll 2
+    for (int idx = tid; idx < 128 * 64; idx += NT) {
+      const int i = idx >> 6, cc = (idx & 63) * 2;
+      *reinterpret_cast<f64x2 *>(Dinv + (off + i) * 256 + off + cc) =
+          *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+      if (half == 0) *reinterpret_cast<f64x2 *>(Dinv + i * 256 + 128 + cc) = (f64x2){0.0, 0.0};
     }
     __syncthreads();
     GOGP_STAMP(half * 8 + 5);
     if (half == 0) {
       // ---- L10 = A10 X00^T, computed as C = X00 * A10^T = L10^T ------------------------
       if (DO_POTRF) {
-        wg_gemm128<true>(c, S, G, A + 128 * ld, ld, tid);
+        wg_gemm128<true, TRI_A>(c, S, G, A + 128 * ld, ld, tid);
+        GOGP_STAMP(27);
+        // S <- L10 (row-major: the transpose of C) for the Schur complement; the factor's
+        // 10-block then goes to global memory from S in whole rows (16-B stores) instead of
+        // 32 scattered 8-B stores per lane
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-              const int i = wr * 32 + m * 16 + fk + 4 * v, j = wc * 64 + n * 16 + fr;
-              Lout[(128 + j) * ldl + i] = c[m][n][v];  // L10[j][i]
-            }
-        // S <- L10 (row-major) for the Schur complement
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int i = wr * 32 + m * 16 + fk + 4 * v, j = wc * 64 + n * 16 + fr;
-              S[j * SLD + i] = c[m][n][v];
+              const int i = GOGP_RT(m) * 16 + fk + 4 * v, j = GOGP_CT(n) * 16 + fr;
+              S[j * SLD + i] = c[m][n][v];  // L10[j][i]
             }
         __syncthreads();
+#pragma unroll 2
+        for (int idx = tid; idx < 128 * 64; idx += NT) {
+          const int i = idx >> 6, cc = (idx & 63) * 2;
+          *reinterpret_cast<f64x2 *>(Lout + (128 + i) * ldl + cc) =
+              *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+        }
       }
     }
   }
   // ---- X10 = -X11 L10 X00 : S = X11 now ------------------------------------------------
   GOGP_STAMP(16);
-  wg_gemm128<false>(c, S, G, L10g, ld10, tid);  // U = X11 * L10
+  wg_gemm128<false, TRI_A>(c, S, G, L10g, ld10, tid);  // U = X11 * L10
   GOGP_STAMP(17);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -466,16 +539,16 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        S[(wr * 32 + m * 16 + fk + 4 * v) * SLD + wc * 64 + n * 16 + fr] = c[m][n][v];
+        S[(GOGP_RT(m) * 16 + fk + 4 * v) * SLD + GOGP_CT(n) * 16 + fr] = c[m][n][v];
   __syncthreads();
-  wg_gemm128<false>(c, S, G, Dinv, 256, tid);  // U * X00
+  wg_gemm128<false, TRI_B>(c, S, G, Dinv, 256, tid);  // U * X00
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        Dinv[(128 + wr * 32 + m * 16 + fk + 4 * v) * 256 + wc * 64 + n * 16 + fr] = -c[m][n][v];
+        Dinv[(128 + GOGP_RT(m) * 16 + fk + 4 * v) * 256 + GOGP_CT(n) * 16 + fr] = -c[m][n][v];
   GOGP_STAMP(18);
 }
 

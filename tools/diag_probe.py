@@ -25,3 +25,5 @@ for k in sorted(names):
 t1, s0, p1, s1, p2 = int(st[1]), int(st[20]), int(st[21]), int(st[21]), int(st[24])
 print("potrf16(0)+solve(0): %d | update+potrf16(1): %d | barrier+solve(1): %d | update+potrf16(2): %d" % (
     s0 - t1, p1 - s0, s1 - p1, p2 - s1))
+print("L10 product %d + epilogue %d | Schur product %d + epilogue %d" % (
+    int(st[27]) - int(st[5]), int(st[8]) - int(st[27]), int(st[26]) - int(st[8]), int(st[9]) - int(st[26])))
