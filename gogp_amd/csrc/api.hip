@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <utility>
 
@@ -72,6 +73,7 @@ struct gogp_handle {
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
   hipStream_t sv = nullptr;  // the chain server (resident diagonal-block workgroup)
+  void *stream_set = nullptr;  // the pooled StreamSet the six streams belong to
   unsigned *chain_flags = nullptr;  // [in: CHAIN_MAX_PANELS | out: CHAIN_MAX_PANELS | err]
   unsigned chain_epoch = 0;
   int chain_server = 0;        // diagonal blocks by the resident server instead of one launch each
@@ -180,6 +182,92 @@ static void free_m_buffers(gogp_handle *h) {
   h->cap_m = h->cap_mp_npad = 0;
 }
 
+// ---- stream sets ------------------------------------------------------------------------
+// A handle works on six streams.  They come from a per-device pool and go back to it when
+// the handle is destroyed; a stream is never destroyed.  Measured reason (tools/
+// handle_probe.py): after hipStreamDestroy, newly created streams get a poor mapping onto
+// the few hardware queues ROCm multiplexes streams on, and every later handle of the
+// process ran 55 % slower at N = 4096 (7.2 ms per evaluation instead of 4.55).  Handles
+// that are alive at the same time get distinct sets.
+struct StreamSet {
+  int device = -1;
+  bool in_use = false;
+  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr, sv = nullptr;
+};
+static std::mutex g_pool_mutex;
+static std::vector<StreamSet *> g_stream_pool;
+
+static hipError_t create_stream_set(StreamSet *ss, int device) {
+  ss->device = device;
+  hipError_t e = hipSuccess;
+  // GOGP_RESERVE_CUS: keep the two big-update streams off some CUs so that the
+  // single-workgroup diagonal kernel (152 KB of LDS: it needs a whole CU) never waits for
+  // them to drain.  Measured: any CU mask costs ~5 % GEMM throughput; default 0 = off.
+  const char *rs = getenv("GOGP_RESERVE_CUS");
+  const int reserve = rs ? atoi(rs) : 0;
+  hipDeviceProp_t prop;
+  std::vector<uint32_t> mask;
+  if (reserve > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+      reserve < prop.multiProcessorCount) {
+    const int ncu = prop.multiProcessorCount;
+    mask.assign((ncu + 31) / 32, 0u);
+    for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+  }
+  if (!mask.empty()) {
+    e = hipExtStreamCreateWithCUMask(&ss->s, (uint32_t)mask.size(), mask.data());
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ss->s2, (uint32_t)mask.size(), mask.data());
+  } else {
+    e = hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ss->s2, hipStreamNonBlocking);
+  }
+  if (e == hipSuccess) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    e = hipStreamCreateWithPriority(&ss->sp, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->st, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sl, hipStreamNonBlocking, least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sv, hipStreamNonBlocking, greatest);
+  }
+  return e;
+}
+
+static hipError_t acquire_streams(gogp_handle *h, int device) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  StreamSet *ss = nullptr;
+  for (StreamSet *c : g_stream_pool)
+    if (!c->in_use && c->device == device) {
+      ss = c;
+      break;
+    }
+  if (!ss) {
+    ss = new StreamSet();
+    const hipError_t e = create_stream_set(ss, device);
+    if (e != hipSuccess) {  // partial sets are not pooled
+      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl, ss->sv})
+        if (q) (void)hipStreamDestroy(q);
+      delete ss;
+      return e;
+    }
+    g_stream_pool.push_back(ss);
+  }
+  ss->in_use = true;
+  h->stream_set = ss;
+  h->s = ss->s;
+  h->s2 = ss->s2;
+  h->sp = ss->sp;
+  h->st = ss->st;
+  h->sl = ss->sl;
+  h->sv = ss->sv;
+  return hipSuccess;
+}
+
+static void release_streams(gogp_handle *h) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (h->stream_set) static_cast<StreamSet *>(h->stream_set)->in_use = false;
+  h->stream_set = nullptr;
+  h->s = h->s2 = h->sp = h->st = h->sl = h->sv = nullptr;
+}
+
 extern "C" void gogp_destroy(gogp_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
@@ -194,11 +282,9 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sv}) {
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl, h->sv})
     if (q) (void)hipStreamSynchronize(q);
-    if (q) (void)hipStreamDestroy(q);
-  }
-  if (h->s) (void)hipStreamDestroy(h->s);
+  release_streams(h);
   (void)hipFree(h->chain_flags);
   delete h;
 }
@@ -235,36 +321,7 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   h->theta_s.assign(h->ns, 0.0);  // gp/gp.go:50-56
   h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) {
-    // The two big-update streams are kept off `reserve` CUs so that the panel
-    // stream's single-workgroup diagonal kernel (152 KB of LDS: it needs a whole
-    // CU) never waits for the GEMM streams to drain.
-    const char *rs = getenv("GOGP_RESERVE_CUS");
-    const int reserve = rs ? atoi(rs) : 0;  // measured: any mask costs ~5 % GEMM throughput
-    hipDeviceProp_t prop;
-    std::vector<uint32_t> mask;
-    if (reserve > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-        reserve < prop.multiProcessorCount) {
-      const int ncu = prop.multiProcessorCount;
-      mask.assign((ncu + 31) / 32, 0u);
-      for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-    }
-    if (!mask.empty()) {
-      e = hipExtStreamCreateWithCUMask(&h->s, (uint32_t)mask.size(), mask.data());
-      if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&h->s2, (uint32_t)mask.size(), mask.data());
-    } else {
-      e = hipStreamCreateWithFlags(&h->s, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking);
-    }
-  }
-  if (e == hipSuccess) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    e = hipStreamCreateWithPriority(&h->sp, hipStreamNonBlocking, greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->sl, hipStreamNonBlocking, least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->sv, hipStreamNonBlocking, greatest);
-  }
+  if (e == hipSuccess) e = acquire_streams(h, device);
   if (e == hipSuccess) e = hipMalloc(&h->chain_flags, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
   if (e == hipSuccess) e = hipMemset(h->chain_flags, 0, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));

@@ -465,6 +465,28 @@ def test_chain_server_option_same_results(gpmod):
         np.testing.assert_array_equal(o[4], out[0][4])
 
 
+def test_later_handles_as_fast_as_the_first(gpmod):
+    """Stream sets are pooled (api.hip): a GP created after others were closed must run as
+    fast as the first one.  With hipStreamDestroy + fresh streams every later handle of the
+    process ran 55 % slower at N = 4096 (poor stream -> hardware-queue mapping)."""
+    import time
+    from gogp_amd import synth
+    n, D = 4096, 8
+    X, y = synth.make_inputs(n, D, 3)
+    best = []
+    for _ in range(3):
+        g = gpmod.GP(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=X, Y=y)
+        ts = []
+        for k in range(4):
+            t = time.perf_counter()
+            g.Observe(synth.log_theta_cycle(D, k))
+            g.Gradient()
+            ts.append(time.perf_counter() - t)
+        best.append(min(ts))
+        g.close()
+    assert max(best[1:]) <= 1.3 * best[0], best
+
+
 def test_handle_reuse_across_sizes_and_call_orders(gpmod):
     """One GP value reused with growing and shrinking data, every call order the API
     allows (Observe -> Gradient twice, Observe -> Observe, Observe -> Absorb -> Produce,
