@@ -431,7 +431,7 @@ static int upload_params(gogp_handle *h) {
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_BASE = 8 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_W = 6, EV_BASE = 8 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static hipEvent_t ev(gogp_handle *h, size_t i) {
@@ -553,6 +553,10 @@ static int factorize(gogp_handle *h, bool eager) {
   const int SW = h->superpanel;
   // working copy of y for the forward substitution (runs on the panel stream)
   HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
+  // The forward substitution z = L^-1 y needs each panel once it is final and nothing
+  // needs z before the end: it runs on the low-priority stream, off the chain.
+  hipStream_t sz = h->lookahead ? h->sl : sp;
+  if (sz != sp) order(h, EV_W, sp, sz);
   // Right-looking blocked Cholesky in super-panels of SW 256-wide panels: the
   // dependency chain (diagonal blocks, panel solves, updates inside the
   // super-panel) runs on the panel stream with 256-wide steps; the trailing
@@ -585,26 +589,30 @@ static int factorize(gogp_handle *h, bool eager) {
                         ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
     }
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
-    // the forward substitution steps of these panels fill the panel stream's wait
-    // for the next block columns
+    if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
     for (int q = 0; q < nsub; ++q)
-      launch_trsv_fwd_step(sp, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
-    // ---- trailing update, rank nsub*256 (main stream) ----------------------------------
+      launch_trsv_fwd_step(sz, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
+    // ---- trailing update, rank nsub*256 ------------------------------------------------------
     const int mtE = (int)((npad - CE) / TILE);
     if (mtE > 0) {
       const int64_t Kw = CE - C0;
       const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
-      // next super-panel's block columns first, each from its diagonal block down
+      // The next super-panel's block columns, each from its diagonal block down, stay on the
+      // CHAIN stream: the critical path (diag -> panel solve -> these updates -> diag) then
+      // never crosses streams (two event hops of ~15 us per super-panel otherwise).  They
+      // only wait for the previous super-panel's bulk update of these columns, which in
+      // steady state finished long ago.
+      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
       for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
-        launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0, ld,
+        launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0, ld,
                         L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
-      order(h, EV_BASE + 4 * P0 + 1, s, sp);  // next super-panel may start
-      // the rest of the trailing matrix, lower tiles only
+      // the rest of the trailing matrix, lower tiles only (main stream)
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
       }
+      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
     }
     // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
@@ -629,7 +637,7 @@ static int factorize(gogp_handle *h, bool eager) {
     h->trtri_done = true;
     h->trtri_pending = true;
   }
-  order(h, EV_FWD, sp, s);  // z complete
+  order(h, EV_FWD, sz, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -644,6 +652,7 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipEventRecord(ev(h, EV_TRTRI), st);
   } else {
     // backward substitution alpha = L^-T z on the panel stream: not needed for LML
+    if (sz != sp) (void)hipStreamWaitEvent(sp, ev(h, EV_FWD), 0);
     HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
     for (int b = npanel - 1; b >= 0; --b)
       launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
