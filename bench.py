@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--nobs", type=int, default=16384)
     ap.add_argument("--ndim", type=int, default=8)
     ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--no-produce", action="store_true",
+                    help="skip the secondary Produce measurement (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=240)
@@ -223,7 +225,7 @@ def main():
                         "sustained v_mfma_f64 issue-rate microbenchmark on this device",
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_produce:
             # secondary metric: Produce throughput at the same N, M = 1024 fresh
             # test points per call, host Z in / host mu, sigma out -- outside the timed region
             Zp = synth.make_test_points(1024, D, seed + 1)
