@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][BT * GEMM_BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wid = tid >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile bases stay in SGPRs
 
   // ---- tile assignment ----------------------------------------------------
   int t = blockIdx.x;
@@ -144,8 +144,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 
   // C fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WTN;
-  const int ccol = lane & 15;
-  const int crow = lane >> 4;
+  // address = wave-uniform row base (SGPRs) + ONE 32-bit per-lane offset + immediate: per-lane
+  // 64-bit row pointers kept across the k loop spill, and a spill reload in the epilogue
+  // waits (vmcnt counts stores too) for every C store issued before it
+  const int coff = (lane >> 4) * (int)g.ldc + (lane & 15);
   const double alpha = g.alpha;
 
   f64x2 ra[NQ], rb[NQ];
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-          acc[m][n][v] = sc * Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol];
+          acc[m][n][v] = sc * (Cg + (long)(m * 16 + 4 * v) * g.ldc)[coff + n * 16];
   } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        Cg[(long)(m * 16 + crow + 4 * v) * g.ldc + n * 16 + ccol] = alpha * acc[m][n][v];
+        (Cg + (long)(m * 16 + 4 * v) * g.ldc)[coff + n * 16] = alpha * acc[m][n][v];
 }
 
 // GOGP_GEMM_W8 = 0 / 1 forces the 4-wave / 8-wave 128-tile kernel (A/B measurements);
