@@ -771,9 +771,8 @@ static int factorize_dist(gogp_handle *h) {
     const int64_t prow = npad - C0;  // packed panel rows C0 .. npad
     const size_t pbytes = (size_t)prow * Kw * sizeof(double);
     if (owner == me) {
-      // my block columns [C0, CE) are up to date once my "next columns" update of the
-      // previous super-panel is done
-      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
+      // my block columns [C0, CE) are up to date: their last update ran on this (panel)
+      // stream, in order, at the end of the previous super-step
       for (int q = 0; q < nsub; ++q) {
         const int p = P0 + q;
         const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
@@ -808,17 +807,22 @@ static int factorize_dist(gogp_handle *h) {
     const int mtE = (int)((npad - CE) / TILE);
     if (mtE > 0) {
       const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
-      if (dist_owner(h, P0 + SW) == me)  // next super-panel: its owner updates it first
+      if (dist_owner(h, P0 + SW) == me) {
+        // the next super-panel is mine: its block columns get this panel's update on the
+        // PANEL stream (the chain never crosses streams); they were last touched by my bulk
+        // update of the previous super-step
+        if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
         for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
-          launch_dgemm_nt(s, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0,
+          launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0,
                           ld, L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
-      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);
+      }
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
         launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf, 0, 0, &own);
       }
+      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // my bulk update of super-step P0 done
     }
   }
   order(h, EV_FWD, sp, s);
