@@ -43,7 +43,10 @@ class ShardedGP(GP):
                 # group-relative root -> global rank
                 src = dist.get_global_rank(group, root) if group is not None else root
                 dist.broadcast(view, src=src, group=group)
-                torch.cuda.synchronize()
+                # Wait for the collective only: the library's own streams (non-blocking, so
+                # the null stream does not join them) keep running this rank's bulk update
+                # meanwhile; a device-wide synchronize here would serialise the two.
+                torch.cuda.current_stream().synchronize()
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 self._cb_error = e
