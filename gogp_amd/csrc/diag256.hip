@@ -61,9 +61,12 @@ __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
 // redundantly (write_diag = false).  Writes the factor block (upper zeroed), 1/L_jj to
 // rinv[0..15] (LDS) and the solved rows back to S; the columns form one basic block (the
 // not-positive-definite test is branch-free and reported once at the end).
-__device__ __forceinline__ void panel16(double *S, int kb, double *rinv, int lane, int row0,
-                                        bool write_diag, long grow0, long nvalid,
-                                        long long *info) {
+// The factored diagonal block is NOT written here: the other waves of the step read the
+// unfactored block at the start of their own pass, so wave 0 keeps its rows (keep[], mine)
+// and stores them with panel16_store_diag after the next barrier.
+__device__ __forceinline__ void panel16(double *S, int kb, int lane, int row0, bool report,
+                                        long grow0, long nvalid, long long *info,
+                                        double (&keep)[16], double &keep_rinv) {
   const int r = lane & 15;
   const bool prow = lane >= 16;                      // panel-row lane
   const int row = prow ? row0 + lane - 16 : kb * 16 + r;
@@ -92,18 +95,26 @@ __device__ __forceinline__ void panel16(double *S, int kb, double *rinv, int lan
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] -= lrj * readlane_d(lrj, c);
   }
-  if (prow) {
-    if (live) {
+  if (prow && live) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) src[c] = a[c];
-    }
-  } else if (write_diag) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) src[c] = (c <= r) ? a[c] : 0.0;
-    rinv[r] = mine;
+    for (int c = 0; c < 16; ++c) src[c] = a[c];
   }
-  if (write_diag && bad < 16 && lane == 0 && grow0 + bad < nvalid && *info == 0)
+#pragma unroll
+  for (int c = 0; c < 16; ++c) keep[c] = a[c];
+  keep_rinv = mine;
+  if (report && bad < 16 && lane == 0 && grow0 + bad < nvalid && *info == 0)
     *info = (long long)(grow0 + bad + 1);
+}
+
+// lanes 0..15 of wave 0: factor block (upper zeroed) and 1/L_jj, after the step's barrier
+__device__ __forceinline__ void panel16_store_diag(double *S, int kb, double *rinv, int lane,
+                                                   const double (&keep)[16], double keep_rinv) {
+  if (lane < 16) {
+    double *dst = S + (kb * 16 + lane) * SLD + kb * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c] = (c <= lane) ? keep[c] : 0.0;
+    rinv[lane] = keep_rinv;
+  }
 }
 
 // Inverse of the 16x16 lower-triangular diagonal block kb of S by ONE wave (lane c
@@ -166,18 +177,22 @@ __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long 
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   // rows below block kb: (7-kb)*16; wave w < 3 carries rows (kb+1)*16 + 48w .. +47
-  if (w < 3) panel16(S, 0, rinv, lane, 16 + 48 * w, w == 0, grow0, nvalid, info);
+  double keep[16], keep_rinv = 0.0;
+  if (w < 3) panel16(S, 0, lane, 16 + 48 * w, w == 0, grow0, nvalid, info, keep, keep_rinv);
   if (st && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   for (int kb = 0; kb < 7; ++kb) {
+    // diagonal block kb: every wave of the previous step has read it (barrier above); its
+    // next readers are the 16x16 inverses after the loop
+    if (w == 0) panel16_store_diag(S, kb, rinv + kb * 16, lane, keep, keep_rinv);
     // ---- A: column block kb+1: tiles (i, kb+1), i = kb+1 .. 7 ---------------------------
     if (kb + 1 + w < 8) tile_update16(S, kb + 1 + w, kb + 1, kb, fr, fk);
     __syncthreads();
     // ---- B -------------------------------------------------------------------------------
     if (w < 3) {
       if ((kb + 2) * 16 + 48 * w < 128 || w == 0)
-        panel16(S, kb + 1, rinv + (kb + 1) * 16, lane, (kb + 2) * 16 + 48 * w, w == 0,
-                grow0 + (kb + 1) * 16, nvalid, info);
+        panel16(S, kb + 1, lane, (kb + 2) * 16 + 48 * w, w == 0, grow0 + (kb + 1) * 16, nvalid,
+                info, keep, keep_rinv);
       if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
     } else {
       // tiles (i, c), kb+2 <= c <= i <= 7, dealt to waves 3..7
@@ -192,6 +207,8 @@ __device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long 
     }
     __syncthreads();
   }
+  if (w == 0) panel16_store_diag(S, 7, rinv + 7 * 16, lane, keep, keep_rinv);
+  __syncthreads();
   // ---- the eight 16x16 inverses, one wave each ----------------------------------------
   inv16<true>(S, w, XD + w * 16 * XLD, rinv + w * 16, lane);
   __syncthreads();
