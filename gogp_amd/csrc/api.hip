@@ -431,7 +431,7 @@ static int upload_params(gogp_handle *h) {
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_W = 6, EV_BASE = 8 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_W = 6, EV_ENTRY = 7, EV_BASE = 8 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static hipEvent_t ev(gogp_handle *h, size_t i) {
@@ -524,7 +524,10 @@ static int factorize(gogp_handle *h, bool eager) {
   if (rc != GOGP_OK) return rc;
   if (eager && !h->bufY)
     HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
-  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
+  // the panel stream joins whatever the main stream still holds from the previous call
+  // (bufA's last readers) and the parameter upload
+  if (sp != s) order(h, EV_ENTRY, s, sp);
+  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), sp));
   const int npanel_all = (int)(npad / PANEL);
   // The chain server goes out first, while the GPU has an empty CU for it; it reads
   // *info's zero and the Gram matrix only after flag 0 is raised behind both.
@@ -538,8 +541,12 @@ static int factorize(gogp_handle *h, bool eager) {
     launch_diag256_server(h->sv, h->bufA, ld, h->bufL, ld, h->Dinv, npanel_all, h->n, h->info,
                           flag_in, flag_out, flag_err, epoch);
   }
-  launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
-  order(h, EV_GRAM, s, sp);
+  // Gram matrix: the first super-panel's block columns on the panel stream -- the chain
+  // starts ~30 us later instead of after the whole 0.5 ms build -- the rest on the main stream
+  launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld,
+                          (int64_t)h->superpanel * PANEL);
+  (void)hipEventRecord(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
+                                            // is NOT implied: consumers of columns < 512 are on sp)
   if (eager) {
     // R := 0 on the strictly upper block triangle (after whatever used bufA last)
     (void)hipStreamWaitEvent(s2, ev(h, EV_GRAM), 0);
@@ -602,7 +609,7 @@ static int factorize(gogp_handle *h, bool eager) {
       // never crosses streams (two event hops of ~15 us per super-panel otherwise).  They
       // only wait for the previous super-panel's bulk update of these columns, which in
       // steady state finished long ago.
-      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
+      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * (P0 - SW) + 1 : EV_GRAM), 0);
       for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
         launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0, ld,
                         L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);

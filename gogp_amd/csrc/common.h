@@ -66,6 +66,9 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
+                             int64_t wcols);
 // KsT (mpad x npad): KsT[j][i] = k(x_i, z_j); zero for i >= n or j >= m.
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
                   int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT,

@@ -21,7 +21,8 @@ template <bool CROSS>
 __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__ Pp,
                                                    const double *__restrict__ Rsrc, long nrows,
                                                    const double *__restrict__ Csrc, long ncols,
-                                                   double *__restrict__ Out, long ld, int ntc) {
+                                                   double *__restrict__ Out, long ld, int ntc,
+                                                   int strip_w, int toff) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -32,12 +33,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
   if (CROSS) {
     ti = blockIdx.x / ntc;
     tj = blockIdx.x - ti * ntc;
+  } else if (strip_w > 0) {
+    // the first strip_w tile columns of the lower triangle (all rows; the few tiles above
+    // the diagonal exit)
+    ti = blockIdx.x / strip_w;
+    tj = blockIdx.x - ti * strip_w;
+    if (ti < tj) return;  // whole-workgroup exit
   } else {
+    // lower triangle of the tile grid shifted by toff tile rows / columns
     const int t = blockIdx.x;
     ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while (ti * (ti + 1) / 2 > t) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
+    ti += toff;
+    tj += toff;
   }
   const long r0 = (long)ti * 64, c0 = (long)tj * 64;
   for (int idx = tid; idx < 64 * D; idx += 256) {
@@ -82,7 +92,25 @@ void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double
   const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
   hipLaunchKernelGGL(gram_kernel<false>, dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
-                     (long)n, K, (long)ld, nt);
+                     (long)n, K, (long)ld, nt, 0, 0);
+}
+
+// The same lower triangle in two launches: block columns [0, wcols) on `s_first` (the panel
+// chain can start on them while the rest is still being written), the remaining triangle on
+// `s_rest`.  wcols is a multiple of 64.
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
+                             int64_t wcols) {
+  const int nt = (int)(npad / 64);
+  int w = (int)(wcols / 64);
+  if (w > nt) w = nt;
+  const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
+  hipLaunchKernelGGL(gram_kernel<false>, dim3(nt * w), dim3(256), lds, s_first, p, X, (long)n, X,
+                     (long)n, K, (long)ld, nt, w, 0);
+  const int nr = nt - w;
+  if (nr > 0)
+    hipLaunchKernelGGL(gram_kernel<false>, dim3(nr * (nr + 1) / 2), dim3(256), lds, s_rest, p, X,
+                       (long)n, X, (long)n, K, (long)ld, nt, 0, w);
 }
 
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -91,7 +119,7 @@ void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, 
   const int ntr = (int)(mpad / 64), ntc = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
   hipLaunchKernelGGL(gram_kernel<true>, dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
-                     (long)n, KsT, (long)ld, ntc);
+                     (long)n, KsT, (long)ld, ntc, 0, 0);
 }
 
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
