@@ -441,6 +441,37 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
     g.close()
 
 
+@pytest.mark.parametrize("opts", [
+    {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"superpanel": 4},
+    {"chain_server": 1, "eager": 0}, {"lauum_split": 50}, {"lookahead": 0, "superpanel": 4},
+], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
+@pytest.mark.parametrize("n", [300, 2300])
+def test_schedule_options_same_results(gpmod, opts, n):
+    """Every scheduling option (stream layout, super-panel width, lazy inverse, chain server,
+    split LAUUM) computes the same numbers as the default schedule; only the grouping of the
+    rank-k updates -- hence rounding -- may differ."""
+    rng = np.random.default_rng(n)
+    D = 3
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(0, 1, (11, D))
+    x = np.log([1.1, 0.5, 0.2])
+    ref = gpmod.GP(D, kernel.Scaled(kernel.Matern52), kernel.UniformNoise, X=X, Y=y)
+    lml0, g0 = ref.Observe(x), ref.Gradient()
+    mu0, sg0 = ref.Produce(Z)
+    g = gpmod.GP(D, kernel.Scaled(kernel.Matern52), kernel.UniformNoise, X=X, Y=y)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    for _ in range(2):  # twice: state carried from one evaluation into the next
+        lml, grad = g.Observe(x), g.Gradient()
+        mu, sg = g.Produce(Z)
+        assert abs(lml - lml0) <= 1e-10 * max(1.0, abs(lml0))
+        np.testing.assert_allclose(grad, g0, rtol=1e-8, atol=1e-8 * np.abs(g0).max())
+        np.testing.assert_allclose(mu, mu0, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(sg, sg0, rtol=1e-8, atol=1e-11)
+    g.close()
+    ref.close()
+
+
 def test_chain_server_option_same_results(gpmod):
     """The resident chain server (one persistent workgroup factoring the diagonal blocks,
     flag-driven) gives bit-identical results to one launch per block."""
