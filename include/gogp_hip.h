@@ -218,7 +218,18 @@ int gogp_profile_enable(gogp_handle *h, int on);
 int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
                       double *gemm_flops, double *gemm_busy_ms);
 
-/* Tuning knobs: name in {"lookahead","nb"}; returns GOGP_EARG if unknown. */
+/* Scheduling knobs (the results do not depend on them beyond rounding; the defaults are the
+ * measured optimum).  Unknown name or out-of-range value: GOGP_EARG.
+ *   "lookahead"    1 | 0   panel chain on its own high-priority stream / everything in order
+ *                          on one stream                                           (default 1)
+ *   "eager"        1 | 0   Observe also runs the triangular inverse (gradient preparation)
+ *                          behind the Cholesky sweep / Gradient computes it lazily  (default 1)
+ *   "superpanel"   1..4    256-wide panels per trailing update (K = 256 * value)    (default 2)
+ *   "lauum_split"  0..95   percent of N whose part of K^-1 = Y Y^T is summed during the
+ *                          sweep's tail; 0 = off                                    (default 0)
+ *   "chain_server" 0 | 1   diagonal blocks factored by one resident workgroup driven by flags
+ *                          instead of one launch per block                          (default 0)
+ * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 
 /* Library build info: "gogp_hip <version> gfx950 ..." */
