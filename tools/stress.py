@@ -1,0 +1,55 @@
+"""Randomised stress run of the HIP path against the CPU oracle (not part of the test suite):
+random sizes, kernel families, schedule options and call orders on reused handles."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from cases import CASES
+from gogp_amd import gp as G
+from oracle.oracle import FastOracle
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + seconds
+OPTS = [{}, {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"chain_server": 1},
+        {"lauum_split": 60}, {"superpanel": 4, "eager": 0}]
+nrun = 0
+worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
+while time.time() < t_end:
+    name, D, simil, noise, ts, tn = CASES[rng.integers(0, len(CASES) - 1)]  # skip default_noise (cond 1e10)
+    opts = OPTS[rng.integers(0, len(OPTS))]
+    g = G.GP(D, simil, noise)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    o = FastOracle(D, simil, noise)
+    for rep in range(int(rng.integers(1, 5))):       # the same handle with changing data sizes
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
+        X = rng.uniform(0, 1, (n, D))
+        y = np.sin(2 * np.pi * X).sum(1) / np.sqrt(D) + 0.1 * rng.normal(size=n)
+        if n > 1:
+            y = (y - y.mean()) / y.std()
+        x = np.log(np.array(list(ts) + list(tn)) * np.exp(0.1 * rng.normal(size=len(ts) + len(tn))))
+        g.X, g.Y = X, y
+        o.set_data(X, y)
+        order = rng.integers(0, 3)
+        lml = g.Observe(x)
+        if order == 1:
+            lml = g.Observe(x)                       # Observe twice, gradient of the second
+        grad = g.Gradient()
+        if order == 2:
+            grad = g.Gradient()                      # Gradient twice
+        Z = rng.uniform(-0.1, 1.1, (int(rng.integers(1, 300)), D))
+        mu, sigma = g.Produce(Z)
+        lml_o = o.Observe(x); grad_o = o.Gradient(); mu_o, sigma_o = o.Produce(Z)
+        e = {"lml": abs(lml - lml_o) / max(1.0, abs(lml_o)),
+             "grad": np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
+             "mu": np.abs(mu - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
+             "sigma": np.nanmax(np.abs(sigma - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
+        for k in e:
+            worst[k] = max(worst[k], float(e[k]))
+        if e["lml"] > 1e-8 or e["grad"] > 1e-6 or e["mu"] > 1e-6 or e["sigma"] > 1e-5:
+            print("MISMATCH", name, n, opts, order, e, flush=True)
+            sys.exit(1)
+        nrun += 1
+    g.close()
+print("stress: %d evaluations OK in %.0f s; worst relative errors %s" % (nrun, seconds, worst), flush=True)
