@@ -58,10 +58,26 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * GEMM_BK + ((chunk ^ ((row >> 1) & 7)) << 1);
 }
 
+// device-only builtins behind helpers: in the host pass of hipcc the unknown builtin
+// silently suppresses the kernel's host stub (undefined __device_stub__ at load time)
+__device__ __forceinline__ void load16_to_lds(const double *gsrc, double *lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void wait_vmcnt0() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
+#endif
+}
+
 // BT = workgroup tile (128 or 64).  NW = 4: 2x2 waves, each (BT/2)x(BT/2) outputs =
 // MT x MT MFMA tiles, MT = BT/32.  NW = 8 (BT = 128): 2x4 waves, each 64x32 outputs:
 // half the accumulators per wave (<= 128 VGPRs), so four waves fit on a SIMD.
-template <int MODE, int BT, int NW>
+// DIRECT: operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write): a wave's 64 lanes x 16 B land on 1 KB of consecutive LDS = 8 rows of the tile,
+// so the XOR swizzle is applied on the GLOBAL side (lane (row, pos) fetches chunk pos ^ swz(row)).
+template <int MODE, int BT, int NW, bool DIRECT>
 __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   constexpr int MT = BT / 32;                          // MFMA tiles per wave, rows
   constexpr int NTW = (NW == 8) ? BT / 64 : BT / 32;   // MFMA tiles per wave, columns
@@ -119,8 +135,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   // ---- staging map: thread -> (row, 16-B chunk), NQ rows per operand --------
   const int srow = tid >> 3;  // 0..SROWS-1, +SROWS*q
   const int schunk = tid & 7;
-  const double *Ap = Ag + (long)srow * g.lda + schunk * 2;
-  const double *Bp = Bg + (long)srow * g.ldb + schunk * 2;
+  const int gchunk = DIRECT ? (schunk ^ ((srow >> 1) & 7)) : schunk;  // SROWS*q never changes swz
+  const double *Ap = Ag + (long)srow * g.lda + gchunk * 2;
+  const double *Bp = Bg + (long)srow * g.ldb + gchunk * 2;
   const long a_step = (long)SROWS * g.lda, b_step = (long)SROWS * g.ldb;
   int soff[NQ];
 #pragma unroll
@@ -156,8 +173,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   // C read latency overlaps the operand pipeline fill
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
-    rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
+    if (DIRECT) {
+      load16_to_lds(Ap + q * a_step, &lds[0][0][(wid * 8 + SROWS * q) * GEMM_BK]);
+      load16_to_lds(Bp + q * b_step, &lds[0][1][(wid * 8 + SROWS * q) * GEMM_BK]);
+    } else {
+      ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
+      rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
+    }
   }
   f64x4 acc[MT][NTW];
   if (beta != 0.0) {
@@ -175,10 +197,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
   }
+  if (!DIRECT) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    *reinterpret_cast<f64x2 *>(&lds[0][0][soff[q]]) = ra[q];
-    *reinterpret_cast<f64x2 *>(&lds[0][1][soff[q]]) = rb[q];
+    for (int q = 0; q < NQ; ++q) {
+      *reinterpret_cast<f64x2 *>(&lds[0][0][soff[q]]) = ra[q];
+      *reinterpret_cast<f64x2 *>(&lds[0][1][soff[q]]) = rb[q];
+    }
+  } else {
+    wait_vmcnt0();  // the tile is in LDS
   }
   __syncthreads();
 
@@ -190,8 +216,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
       const double *bp = Bp + (long)(kt + 1) * GEMM_BK;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        ra[q] = *reinterpret_cast<const f64x2 *>(ap + q * a_step);
-        rb[q] = *reinterpret_cast<const f64x2 *>(bp + q * b_step);
+        if (DIRECT) {
+          // buffer cur^1 was last read in step kt-1; every wave has passed that step's barrier
+          load16_to_lds(ap + q * a_step, &lds[cur ^ 1][0][(wid * 8 + SROWS * q) * GEMM_BK]);
+          load16_to_lds(bp + q * b_step, &lds[cur ^ 1][1][(wid * 8 + SROWS * q) * GEMM_BK]);
+        } else {
+          ra[q] = *reinterpret_cast<const f64x2 *>(ap + q * a_step);
+          rb[q] = *reinterpret_cast<const f64x2 *>(bp + q * b_step);
+        }
       }
     }
     const double *la = lds[cur][0];
@@ -210,10 +242,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
     if (more) {
+      if (DIRECT) {
+        wait_vmcnt0();
+      } else {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][0][soff[q]]) = ra[q];
-        *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][1][soff[q]]) = rb[q];
+        for (int q = 0; q < NQ; ++q) {
+          *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][0][soff[q]]) = ra[q];
+          *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][1][soff[q]]) = rb[q];
+        }
       }
     }
     __syncthreads();
@@ -232,6 +268,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 
 // GOGP_GEMM_W8 = 0 / 1 forces the 4-wave / 8-wave 128-tile kernel (A/B measurements);
 // unset: 8 waves for the large launches, where they measured 4-9% faster.
+// GOGP_GEMM_DIRECT=0 selects the register-staged operand path (A/B measurements); default:
+// global -> LDS direct loads (+3-4 % on the large GEMMs, -2.3 % time per evaluation).
+static const bool g_gemm_direct = [] {
+  const char *e = getenv("GOGP_GEMM_DIRECT");
+  return !e || atoi(e) != 0;
+}();
+
 static const int g_gemm_w8 = [] {
   const char *e = getenv("GOGP_GEMM_W8");
   return e ? (atoi(e) != 0 ? 1 : 0) : -1;
@@ -303,34 +346,59 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     g.own_col0 *= 2;
     const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
     dim3 grid(n64);
-    if (mode == GEMM_RECT)
-      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4>), grid, block, 0, s, g);
-    else
-      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4>), grid, block, 0, s, g);
+    if (mode == GEMM_RECT) {
+      if (g_gemm_direct)
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4, true>), grid, block, 0, s, g);
+      else
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4, false>), grid, block, 0, s, g);
+    } else {
+      if (g_gemm_direct)
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4, true>), grid, block, 0, s, g);
+      else
+        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4, false>), grid, block, 0, s, g);
+    }
   } else if (g_gemm_w8 == 1 || (g_gemm_w8 < 0 && (mode == GEMM_LAUUM || ntiles >= 3072))) {
     dim3 grid(ntiles), block8(512);
     switch (mode) {
       case GEMM_RECT:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8>), grid, block8, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8, true>), grid, block8, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8, false>), grid, block8, 0, s, g);
         break;
       case GEMM_LOWER:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8>), grid, block8, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8, true>), grid, block8, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8, false>), grid, block8, 0, s, g);
         break;
       case GEMM_LAUUM:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8>), grid, block8, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8, true>), grid, block8, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8, false>), grid, block8, 0, s, g);
         break;
     }
   } else {
     dim3 grid(ntiles);
     switch (mode) {
       case GEMM_RECT:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4>), grid, block, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4, true>), grid, block, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4, false>), grid, block, 0, s, g);
         break;
       case GEMM_LOWER:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4>), grid, block, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4, true>), grid, block, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4, false>), grid, block, 0, s, g);
         break;
       case GEMM_LAUUM:
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4>), grid, block, 0, s, g);
+        if (g_gemm_direct)
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, true>), grid, block, 0, s, g);
+        else
+          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, false>), grid, block, 0, s, g);
         break;
     }
   }
