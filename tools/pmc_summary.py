@@ -1,14 +1,19 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel family."""
 import collections, csv, glob, sys
 
+import re
+
+
 def short(n):
-    for k in ['dgemm_nt_kernel<0, 64, 4>', 'dgemm_nt_kernel<1, 64, 4>', 'dgemm_nt_kernel<0, 128, 4>',
-              'dgemm_nt_kernel<1, 128, 4>', 'dgemm_nt_kernel<2, 128, 4>', 'dgemm_nt_kernel<0, 128, 8>',
-              'dgemm_nt_kernel<1, 128, 8>', 'dgemm_nt_kernel<2, 128, 8>', 'diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y',
-              'zero_upper', 'mfma_f64_peak']:
+    m = re.search(r'dgemm_nt_kernel<(\d), (\d+), (\d), (true|false)>', n)
+    if m:  # MODE, TILE, WAVES (the staging flavour is not distinguished)
+        return 'dgemm_nt_kernel<%s, %s, %s>' % m.group(1, 2, 3)
+    for k in ['diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y', 'zero_upper',
+              'mfma_f64_peak']:
         if k in n:
             return k
     return None
+
 
 for path in sys.argv[1:]:
     f = glob.glob(path + "/*/*_counter_collection.csv")[0]
