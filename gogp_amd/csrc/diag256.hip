@@ -1,5 +1,5 @@
 // diag256.hip -- factor and invert one 256x256 diagonal block in ONE workgroup
-// (512 threads = 8 waves: 256-VGPR budget, no spills, cheap barriers).  This kernel is the serial link of the blocked
+// (512 threads = 8 waves: 256-VGPR budget, cheap barriers).  This kernel is the serial link of the blocked
 // Cholesky's dependency chain (diag -> panel solve -> next-column update -> diag),
 // so it is built for latency: everything O(n^3) inside it runs on
 // v_mfma_f64_16x16x4_f64 from LDS, and the only scalar-serial work left is the
@@ -18,13 +18,22 @@
 // (upper zero-filled), which turns every panel solve of the callers into a
 // single K=256 GEMM  (panel) * Dinv^T.
 //
-// chol(128) is blocked by 16 with in-kernel look-ahead (see potrf128_lds); the
-// 128x128 inverse is assembled from the eight 16x16 inverses by recursive doubling
-// (X21 = -X22 L21 X11 at sizes 16, 32, 64) on MFMA.
+// chol(128) is blocked by 16 (potrf128_lds): per column block, three waves factor the 16x16
+// diagonal block and solve the rows below it in ONE pass (panel16: the panel rows ride in
+// lanes 16..63 of the factoring wave), five waves apply the previous panel to the rest of the
+// matrix with MFMA.  The 128x128 inverse is assembled from the eight 16x16 inverses by
+// recursive doubling (X21 = -X22 L21 X11 at sizes 16, 32, 64) on MFMA.  The four 128^3
+// products (L10, Schur complement, U = X11 L10, X10 = -U X00) skip the zero blocks of their
+// triangular operand / the upper tiles of the symmetric result with a balanced tile map
+// (wg_gemm128); B is staged once per workgroup through LDS, the Schur product reads both
+// operands from S.
+//
+// Timing (tools/diag_probe.py, cycles of s_memtime at 2.36 GHz): 2 x 69K factor, 2 x 22K
+// inverse, 4 products 28-36K each incl. epilogues, 18K plain copies = 144 us per block.
 //
 // LDS: S[128][130] doubles (padding 2 => the MFMA fragment reads of 16 rows x
-// 2 k hit 64 distinct banks), G = 2304 doubles shared by the eight 16x16
-// inverses.
+// 2 k hit 64 distinct banks), G = 2304 doubles: the eight 16x16 inverses during the factor /
+// inverse phases, the double-buffered B chunks during the products.
 #include "common.h"
 
 namespace gogp {
