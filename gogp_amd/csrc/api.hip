@@ -465,9 +465,8 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
   double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   GemmProfile *pf = &h->prof;
   const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
-  // R[0:C0, C0:CE] is final once the previous super-step's next-columns update is done
-  if (P0 > 0 && st != s2)
-    (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (P0 - h->superpanel) + 3), 0);
+  // R[0:C0, C0:CE] is final: its last update (the previous super-step's next-columns update)
+  // ran on this chain stream, in order
   for (int q = 0; q < nsub; ++q) {
     const int p = P0 + q;
     const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
@@ -482,20 +481,24 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
       launch_dgemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
                       Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
   }
-  order(h, EV_BASE + 4 * P0 + 2, st, s2);
+  order(h, EV_BASE + 4 * P0 + 2, st, s2);  // column panels P0.. of Y are final
   const int nt = (int)((npad - CE) / TILE);
   if (nt > 0) {
     const int64_t Kw = CE - C0;
     const int mr = (int)(CE / TILE);
     const int ntn = nt < 2 * h->superpanel ? nt : 2 * h->superpanel;  // next super-panel's columns
-    launch_dgemm_nt(s2, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
+    // The next super-step's columns stay on the CHAIN stream (as in the Cholesky sweep: no
+    // event hop on the chain); they were last touched by the previous super-step's bulk update.
+    if (P0 > 0 && st != s2)
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (P0 - h->superpanel) + 3), 0);
+    launch_dgemm_nt(st, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
                     R + CE, ld, pf);
-    (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);
     if (nt > ntn) {
       const int64_t C3 = CE + (int64_t)ntn * TILE;
       launch_dgemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
                       R + C3, ld, pf);
     }
+    (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);  // bulk R update of super-step P0 done
   }
 }
 
@@ -610,9 +613,11 @@ static int factorize(gogp_handle *h, bool eager) {
       // only wait for the previous super-panel's bulk update of these columns, which in
       // steady state finished long ago.
       (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * (P0 - SW) + 1 : EV_GRAM), 0);
-      for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
-        launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0, ld,
-                        L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      // ONE trapezoid launch for all of them (rows CE.., columns CE .. CE + ntn*128, the
+      // strictly upper 256-blocks -- R of the triangular inverse -- skipped): separate
+      // launches would run one after the other on this in-order stream
+      launch_dgemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
+                      1.0, A + CE * ld + CE, ld, pf);
       // the rest of the trailing matrix, lower tiles only (main stream)
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
@@ -819,9 +824,8 @@ static int factorize_dist(gogp_handle *h) {
         // PANEL stream (the chain never crosses streams); they were last touched by my bulk
         // update of the previous super-step
         if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
-        for (int64_t cr = CE; cr < CE + (int64_t)ntn * TILE; cr += PANEL)
-          launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, Kw, -1.0, L + cr * ld + C0,
-                          ld, L + cr * ld + C0, ld, 1.0, A + cr * ld + cr, ld, pf);
+        launch_dgemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
+                        1.0, A + CE * ld + CE, ld, pf);
       }
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;

@@ -52,7 +52,11 @@ struct GemmOwn {
 };
 
 // ---- launchers implemented in the .hip files ------------------------------
-enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2 };
+enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2,
+                // GEMM_RECT whose tiles in strictly upper 256x256 blocks (block column > block row,
+                // counted from the C origin) are skipped: several adjacent block columns updated
+                // "each from its own diagonal block down" in ONE launch
+                GEMM_TRAP = 3 };
 
 // C(mt*128 x nt*128) = beta*C + alpha * A * B^T, row-major, K multiple of 16.
 // GEMM_LOWER: square tile grid mt x mt, only tiles ti >= tj.

@@ -51,6 +51,7 @@ struct GemmArgs {
   // ((own_col0 + tj) / own_tps) % own_n == own_r  (tile columns counted in units of
   // this kernel's tile, own_tps tiles per super-panel).  LAUUM: iff ti % own_n == own_r.
   int own_n, own_r, own_tps, own_col0;
+  int trap;  // GEMM_TRAP: skip tiles of strictly upper 256-blocks
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   if (MODE == GEMM_RECT) {
     ti = t / g.nt;
     tj = t - ti * g.nt;
+    if (g.trap && (tj * BT) / PANEL > (ti * BT) / PANEL) return;  // whole-workgroup exit
   } else {
     ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while (ti * (ti + 1) / 2 > t) --ti;
@@ -306,7 +308,14 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.own_col0 = own ? own->col0 : 0;
   int ntiles;
   double flops;
-  if (mode == GEMM_RECT) {
+  g.trap = 0;
+  if (mode == GEMM_TRAP) {  // rectangular enumeration, upper 256-blocks skipped in the kernel
+    mode = GEMM_RECT;
+    g.trap = 1;
+    ntiles = mt * nt;
+    const int nb = nt / 2;  // 256-blocks across; block column b skips b block rows of 2 x 2 tiles
+    flops = 2.0 * TILE * TILE * (double)K * ((double)mt * nt - 4.0 * nb * (nb - 1) / 2.0);
+  } else if (mode == GEMM_RECT) {
     ntiles = mt * nt;
     flops = 2.0 * (double)mt * TILE * (double)nt * TILE * (double)K;
   } else {
@@ -378,6 +387,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
         else
           hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8, false>), grid, block8, 0, s, g);
         break;
+      default:
+        break;
     }
   } else {
     dim3 grid(ntiles);
@@ -399,6 +410,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
           hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, true>), grid, block, 0, s, g);
         else
           hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, false>), grid, block, 0, s, g);
+        break;
+      default:
         break;
     }
   }
