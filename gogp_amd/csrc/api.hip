@@ -106,6 +106,7 @@ struct gogp_handle {
       snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                __FILE__, __LINE__);                                                    \
       (h)->err = buf_;                                                                 \
+      (void)hipGetLastError(); /* reset the sticky error: later calls must not see it */ \
       return (e_ == hipErrorOutOfMemory) ? GOGP_ENOMEM : GOGP_EHIP;                     \
     }                                                                                  \
   } while (0)

@@ -518,6 +518,29 @@ def test_later_handles_as_fast_as_the_first(gpmod):
     assert max(best[1:]) <= 1.3 * best[0], best
 
 
+def test_out_of_memory_is_reported_and_recoverable(gpmod):
+    """A problem that does not fit in HBM (N = 140000: three N x N fp64 buffers of 157 GB) fails
+    with GOGP_ENOMEM, and the same handle then works on a small problem (the sticky HIP error of
+    the failed hipMalloc must not leak into later calls)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(9)
+    g = gpmod.GP(2, kernel.Scaled(kernel.Normal), kernel.UniformNoise)
+    n = 140000
+    g.X, g.Y = rng.uniform(0, 1, (n, 2)), rng.normal(size=n)
+    x = np.log([1.0, 0.5, 0.1])
+    with pytest.raises(gpmod.GogpError) as ei:
+        g.Observe(x)
+    assert ei.value.code == 5  # GOGP_ENOMEM
+    X, y = _data(rng, 400, 2)
+    g.X, g.Y = X, y
+    o = FastOracle(2, kernel.Scaled(kernel.Normal), kernel.UniformNoise)
+    o.set_data(X, y)
+    lml, lml_o = g.Observe(x), o.Observe(x)
+    assert abs(lml - lml_o) <= 1e-8 * max(1.0, abs(lml_o))
+    np.testing.assert_allclose(g.Gradient(), o.Gradient(), rtol=1e-6, atol=1e-8)
+    g.close()
+
+
 def test_handle_reuse_across_sizes_and_call_orders(gpmod):
     """One GP value reused with growing and shrinking data, every call order the API
     allows (Observe -> Gradient twice, Observe -> Observe, Observe -> Absorb -> Produce,
