@@ -518,6 +518,28 @@ def test_later_handles_as_fast_as_the_first(gpmod):
     assert max(best[1:]) <= 1.3 * best[0], best
 
 
+@pytest.mark.parametrize("n", [50, 700])
+def test_nan_inputs_behave_like_the_reference(gpmod, n):
+    """NaN in an input row poisons a row/column of K: gonum's Cholesky fails and Absorb / Observe
+    report "not positive definite" (gp/gp.go:228-230) -- here with the poisoned row as pivot.  NaN
+    in an output only reaches alpha: LML and gradient are NaN, no error.  The handle recovers."""
+    rng = np.random.default_rng(n)
+    X, y = _data(rng, n, 2)
+    x = np.log([1.0, 0.5, 0.1])
+    Xn = X.copy()
+    Xn[n // 2, 1] = np.nan
+    g = gpmod.GP(2, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=Xn, Y=y)
+    with pytest.raises(gpmod.FactorizeError):
+        g.Observe(x)
+    yn = y.copy()
+    yn[3] = np.nan
+    g.X, g.Y = X, yn
+    assert math.isnan(g.Observe(x)) and np.isnan(g.Gradient()).all()
+    g.X, g.Y = X, y
+    assert np.isfinite(g.Observe(x)) and np.isfinite(g.Gradient()).all()
+    g.close()
+
+
 def test_out_of_memory_is_reported_and_recoverable(gpmod):
     """A problem that does not fit in HBM (N = 140000: three N x N fp64 buffers of 157 GB) fails
     with GOGP_ENOMEM, and the same handle then works on a small problem (the sticky HIP error of
