@@ -540,6 +540,43 @@ def test_nan_inputs_behave_like_the_reference(gpmod, n):
     g.close()
 
 
+def test_handles_in_concurrent_host_threads(gpmod):
+    """include/gogp_hip.h: calls on one handle are serialised by the caller, different handles
+    may run concurrently.  Four handles driven from four host threads (ctypes releases the GIL)
+    give bitwise the results of running them one after the other."""
+    import threading
+
+    def make(n, seed):
+        r = np.random.default_rng(seed)
+        return _data(r, n, 3)
+
+    cases = [(1500, 1), (2100, 2), (900, 3), (1800, 4)]
+    xs = [np.log([1.0, 0.5, 0.2]) + 0.01 * k for k in range(6)]
+
+    def run(case, out):
+        X, y = make(*case)
+        g = gpmod.GP(3, kernel.Scaled(kernel.Matern32), kernel.UniformNoise, X=X, Y=y)
+        for x in xs:
+            out.append((g.Observe(x), g.Gradient().copy(), g.Produce(X[:5])[0].copy()))
+        g.close()
+
+    seq = [[] for _ in cases]
+    for c, o in zip(cases, seq):
+        run(c, o)
+    par = [[] for _ in cases]
+    ths = [threading.Thread(target=run, args=(c, o)) for c, o in zip(cases, par)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for a, b in zip(seq, par):
+        assert len(a) == len(b) == len(xs)
+        for (l0, g0, m0), (l1, g1, m1) in zip(a, b):
+            assert l0 == l1
+            np.testing.assert_array_equal(g0, g1)
+            np.testing.assert_array_equal(m0, m1)
+
+
 def test_out_of_memory_is_reported_and_recoverable(gpmod):
     """A problem that does not fit in HBM (N = 140000: three N x N fp64 buffers of 157 GB) fails
     with GOGP_ENOMEM, and the same handle then works on a small problem (the sticky HIP error of
