@@ -478,9 +478,13 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
     if (c0 > 0)
       launch_dgemm_nt(st, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
                       Y + c0, ld, pf);
-    if (c2 < CE)
-      launch_dgemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
-                      Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
+    if (c2 < CE) {  // same binary grouping as the Cholesky sweep's updates inside a super-panel
+      const int done = q + 1, grp = done & -done;
+      const int64_t k0 = c2 - (int64_t)grp * PANEL;
+      const int64_t ce = (c2 + (int64_t)grp * PANEL < CE) ? c2 + (int64_t)grp * PANEL : CE;
+      launch_dgemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((ce - c2) / TILE), (int64_t)grp * PANEL,
+                      -1.0, Y + k0, ld, L + c2 * ld + k0, ld, 1.0, R + c2, ld, pf);
+    }
   }
   order(h, EV_BASE + 4 * P0 + 2, st, s2);  // column panels P0.. of Y are final
   const int nt = (int)((npad - CE) / TILE);
@@ -592,12 +596,20 @@ static int factorize(gogp_handle *h, bool eager) {
       if (mt2 > 0)
         launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
                         L + c2 * ld + c0, ld, pf);
-      // remaining block columns of this super-panel, each from its own diagonal block
-      // down (the blocks above belong to R of the fused triangular inverse):
-      // A[cr:, cr:cr+256] -= L[cr:, c0:c2] L[cr:cr+256, c0:c2]^T
-      for (int64_t cr = c2; cr < CE; cr += PANEL)
-        launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0, L + cr * ld + c0,
-                        ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
+      // Updates inside the super-panel, grouped like a binary counter: after panel q the
+      // next g = lowbit(q+1) block columns receive the LAST g panels at once (K = 256 g), each
+      // column from its own diagonal block down (the blocks above belong to R of the fused
+      // triangular inverse) -- one trapezoid launch.  Every block column has all earlier
+      // panels of the super-panel when its turn comes; for two panels per super-panel this is
+      // the single K=256 update of the second column.
+      if (c2 < CE) {
+        const int done = q + 1, grp = done & -done;
+        const int64_t k0 = c2 - (int64_t)grp * PANEL;
+        const int64_t ce = (c2 + (int64_t)grp * PANEL < CE) ? c2 + (int64_t)grp * PANEL : CE;
+        launch_dgemm_nt(sp, GEMM_TRAP, (int)((npad - c2) / TILE), (int)((ce - c2) / TILE),
+                        (int64_t)grp * PANEL, -1.0, L + c2 * ld + k0, ld, L + c2 * ld + k0, ld, 1.0,
+                        A + c2 * ld + c2, ld, pf);
+      }
     }
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
     if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
@@ -1357,7 +1369,7 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     return GOGP_OK;
   }
   if (strcmp(name, "superpanel") == 0) {
-    if (value < 1 || value > 4) return fail(h, GOGP_EARG, "superpanel must be 1..4");
+    if (value < 1 || value > 8) return fail(h, GOGP_EARG, "superpanel must be 1..8");
     h->superpanel = (int)value;
     return GOGP_OK;
   }

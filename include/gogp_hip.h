@@ -224,7 +224,7 @@ int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
  *                          on one stream                                           (default 1)
  *   "eager"        1 | 0   Observe also runs the triangular inverse (gradient preparation)
  *                          behind the Cholesky sweep / Gradient computes it lazily  (default 1)
- *   "superpanel"   1..4    256-wide panels per trailing update (K = 256 * value)    (default 2)
+ *   "superpanel"   1..8    256-wide panels per trailing update (K = 256 * value)    (default 2)
  *   "lauum_split"  0..95   percent of N whose part of K^-1 = Y Y^T is summed during the
  *                          sweep's tail; 0 = off                                    (default 0)
  *   "chain_server" 0 | 1   diagonal blocks factored by one resident workgroup driven by flags

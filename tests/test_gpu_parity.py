@@ -442,7 +442,8 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
 
 
 @pytest.mark.parametrize("opts", [
-    {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"superpanel": 4},
+    {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"superpanel": 4}, {"superpanel": 8},
+    {"superpanel": 6, "eager": 0},
     {"chain_server": 1, "eager": 0}, {"lauum_split": 50}, {"lookahead": 0, "superpanel": 4},
 ], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("n", [300, 2300])
