@@ -346,7 +346,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // Small launches (the skinny GEMMs of the panel chain) use 64x64 tiles: 4x the
   // workgroups and a quarter of the per-tile latency.  LAUUM keeps 128 (its K
   // ranges are cut at 128-row granularity).
-  const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
+  static const int small_limit = getenv("GOGP_SMALL_TILES") ? atoi(getenv("GOGP_SMALL_TILES")) : 384;
+  const bool small = (mode != GEMM_LAUUM) && (ntiles < small_limit);
   dim3 block(256);
   if (small) {
     g.mt = mt * 2;
