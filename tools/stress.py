@@ -51,5 +51,7 @@ while time.time() < t_end:
             print("MISMATCH", name, n, opts, order, e, flush=True)
             sys.exit(1)
         nrun += 1
+        if nrun % 100 == 0:
+            print("  ... %d evaluations OK, %.0f s left" % (nrun, t_end - time.time()), flush=True)
     g.close()
 print("stress: %d evaluations OK in %.0f s; worst relative errors %s" % (nrun, seconds, worst), flush=True)
