@@ -14,6 +14,7 @@ from .kernel import CDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgogp_hip.so")
+HOOKS_PATH = os.path.join(_HERE, "libgogp_testhooks.so")
 
 GOGP_OK, GOGP_EARG, GOGP_ENOTPD, GOGP_EHIP, GOGP_ESTATE, GOGP_ENOMEM = 0, 1, 2, 3, 4, 5
 
@@ -53,6 +54,11 @@ SYMBOLS = [
     ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
     ("gogp_version", ctypes.c_char_p, []),
+]
+
+#: every symbol include/gogp_testhooks.h declares (libgogp_testhooks.so: measurement and
+#: diagnostic hooks for tests/, tools/ and bench.py -- not part of the product ABI)
+HOOK_SYMBOLS = [
     ("gogp_mfma_f64_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
     ("gogp_bench_gemm", ctypes.c_int,
      [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_int, _dp, _dp]),
@@ -77,6 +83,23 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_hooks = None
+
+
+def hooks() -> ctypes.CDLL:
+    """The measurement-hook library (include/gogp_testhooks.h)."""
+    global _hooks
+    if _hooks is None:
+        lib()  # the hook library links the product library
+        if not os.path.exists(HOOKS_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % HOOKS_PATH)
+        L = ctypes.CDLL(HOOKS_PATH)
+        for name, restype, argtypes in HOOK_SYMBOLS:
+            f = getattr(L, name)
+            f.restype = restype
+            f.argtypes = argtypes
+        _hooks = L
+    return _hooks
 
 
 def lib() -> ctypes.CDLL:
@@ -87,7 +110,8 @@ def lib() -> ctypes.CDLL:
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(gogp_amd has no CPU fallback)" % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
+        # RTLD_GLOBAL: libgogp_testhooks.so resolves the internal launchers against it
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, restype, argtypes in SYMBOLS:
             f = getattr(L, name)  # AttributeError if the symbol is not exported
             f.restype = restype

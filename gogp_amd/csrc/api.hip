@@ -53,6 +53,7 @@ struct gogp_handle {
   DevParams *hostP = nullptr;  // pinned
   double *hscal = nullptr;     // pinned staging, NACC + 16 doubles
   int64_t cap_npad = 0;        // allocation size of the N-dependent buffers
+  int64_t cap_y = 0;           // npad bufY was allocated for (it is allocated lazily)
   // produce workspace
   double *dZ = nullptr, *KsT = nullptr, *Vt = nullptr, *pvec = nullptr;
   int64_t cap_m = 0, cap_mp_npad = 0;
@@ -66,18 +67,10 @@ struct gogp_handle {
   void *dist_user = nullptr;
   double *dist_staging = nullptr;
   int64_t dist_staging_bytes = 0;
-  hipStream_t sl = nullptr;  // early part of K^-1 = Y Y^T (split LAUUM) during the sweep's tail
-  int lauum_split_pct = 0;   // K range [0, pct% of N) of LAUUM summed during the sweep; 0 = off
-                             // (measured: no gain, the sweep is already throughput-bound)
-  int64_t lauum_ksplit = 0;  // columns already summed by the early part (this evaluation)
+  hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
-  hipStream_t sv = nullptr;  // the chain server (resident diagonal-block workgroup)
-  void *stream_set = nullptr;  // the pooled StreamSet the six streams belong to
-  unsigned *chain_flags = nullptr;  // [in: CHAIN_MAX_PANELS | out: CHAIN_MAX_PANELS | err]
-  unsigned chain_epoch = 0;
-  int chain_server = 0;        // diagonal blocks by the resident server instead of one launch each
-                               // (measured: removes the placement waits, no end-to-end gain; option)
+  void *stream_set = nullptr;  // the pooled StreamSet the five streams belong to
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
   int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
@@ -172,6 +165,7 @@ static void free_n_buffers(gogp_handle *h) {
   h->dX = h->dy = h->bufA = h->bufL = h->bufY = h->Dinv = nullptr;
   h->z = h->w = h->alpha = h->gpart = nullptr;
   h->cap_npad = 0;
+  h->cap_y = 0;
 }
 
 static void free_m_buffers(gogp_handle *h) {
@@ -184,7 +178,7 @@ static void free_m_buffers(gogp_handle *h) {
 }
 
 // ---- stream sets ------------------------------------------------------------------------
-// A handle works on six streams.  They come from a per-device pool and go back to it when
+// A handle works on five streams.  They come from a per-device pool and go back to it when
 // the handle is destroyed; a stream is never destroyed.  Measured reason (tools/
 // handle_probe.py): after hipStreamDestroy, newly created streams get a poor mapping onto
 // the few hardware queues ROCm multiplexes streams on, and every later handle of the
@@ -193,7 +187,7 @@ static void free_m_buffers(gogp_handle *h) {
 struct StreamSet {
   int device = -1;
   bool in_use = false;
-  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr, sv = nullptr;
+  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr;
 };
 static std::mutex g_pool_mutex;
 static std::vector<StreamSet *> g_stream_pool;
@@ -201,33 +195,14 @@ static std::vector<StreamSet *> g_stream_pool;
 static hipError_t create_stream_set(StreamSet *ss, int device) {
   ss->device = device;
   hipError_t e = hipSuccess;
-  // GOGP_RESERVE_CUS: keep the two big-update streams off some CUs so that the
-  // single-workgroup diagonal kernel (152 KB of LDS: it needs a whole CU) never waits for
-  // them to drain.  Measured: any CU mask costs ~5 % GEMM throughput; default 0 = off.
-  const char *rs = getenv("GOGP_RESERVE_CUS");
-  const int reserve = rs ? atoi(rs) : 0;
-  hipDeviceProp_t prop;
-  std::vector<uint32_t> mask;
-  if (reserve > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-      reserve < prop.multiProcessorCount) {
-    const int ncu = prop.multiProcessorCount;
-    mask.assign((ncu + 31) / 32, 0u);
-    for (int c = reserve; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-  }
-  if (!mask.empty()) {
-    e = hipExtStreamCreateWithCUMask(&ss->s, (uint32_t)mask.size(), mask.data());
-    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ss->s2, (uint32_t)mask.size(), mask.data());
-  } else {
-    e = hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ss->s2, hipStreamNonBlocking);
-  }
+  e = hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ss->s2, hipStreamNonBlocking);
   if (e == hipSuccess) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     e = hipStreamCreateWithPriority(&ss->sp, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->st, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sl, hipStreamNonBlocking, least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sv, hipStreamNonBlocking, greatest);
   }
   return e;
 }
@@ -244,7 +219,7 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
     ss = new StreamSet();
     const hipError_t e = create_stream_set(ss, device);
     if (e != hipSuccess) {  // partial sets are not pooled
-      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl, ss->sv})
+      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl})
         if (q) (void)hipStreamDestroy(q);
       delete ss;
       return e;
@@ -258,7 +233,6 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
   h->sp = ss->sp;
   h->st = ss->st;
   h->sl = ss->sl;
-  h->sv = ss->sv;
   return hipSuccess;
 }
 
@@ -266,7 +240,7 @@ static void release_streams(gogp_handle *h) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   if (h->stream_set) static_cast<StreamSet *>(h->stream_set)->in_use = false;
   h->stream_set = nullptr;
-  h->s = h->s2 = h->sp = h->st = h->sl = h->sv = nullptr;
+  h->s = h->s2 = h->sp = h->st = h->sl = nullptr;
 }
 
 extern "C" void gogp_destroy(gogp_handle *h) {
@@ -283,10 +257,9 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl, h->sv})
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl})
     if (q) (void)hipStreamSynchronize(q);
   release_streams(h);
-  (void)hipFree(h->chain_flags);
   delete h;
 }
 
@@ -323,8 +296,6 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = acquire_streams(h, device);
-  if (e == hipSuccess) e = hipMalloc(&h->chain_flags, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(h->chain_flags, 0, (2 * CHAIN_MAX_PANELS + 1) * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
@@ -432,7 +403,7 @@ static int upload_params(gogp_handle *h) {
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_LAUUM1 = 5, EV_W = 6, EV_ENTRY = 7, EV_BASE = 8 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_BASE = 8 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static hipEvent_t ev(gogp_handle *h, size_t i) {
@@ -449,6 +420,19 @@ static void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
   hipEvent_t e = ev(h, i);
   (void)hipEventRecord(e, from);
   (void)hipStreamWaitEvent(to, e, 0);
+}
+
+// bufY (Y = L^-T) is allocated on first use and tracked by its own capacity: the other
+// N-dependent buffers may have been sized by an Absorb that never needed it.
+static int ensure_y(gogp_handle *h) {
+  if (h->bufY && h->cap_y >= h->npad) return GOGP_OK;
+  (void)hipFree(h->bufY);
+  h->bufY = nullptr;
+  h->cap_y = 0;
+  const int64_t cap = std::max(h->npad, h->cap_npad);
+  HIPCHK(h, hipMalloc(&h->bufY, (size_t)cap * (size_t)cap * sizeof(double)));
+  h->cap_y = cap;
+  return GOGP_OK;
 }
 
 // ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
@@ -521,34 +505,20 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipStreamWaitEvent(sp, ev(h, EV_TRTRI), 0);
     h->trtri_pending = false;
   }
-  // ... and possibly the early LAUUM part (writes bufA, reads Y)
-  if (h->lauum_ksplit > 0) (void)hipStreamWaitEvent(s, ev(h, EV_LAUUM1), 0);
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
   h->trtri_done = false;
-  h->lauum_ksplit = 0;
   h->notpd = -1;
   int rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
-  if (eager && !h->bufY)
-    HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+  if (eager) {
+    rc = ensure_y(h);
+    if (rc != GOGP_OK) return rc;
+  }
   // the panel stream joins whatever the main stream still holds from the previous call
   // (bufA's last readers) and the parameter upload
   if (sp != s) order(h, EV_ENTRY, s, sp);
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), sp));
-  const int npanel_all = (int)(npad / PANEL);
-  // The chain server goes out first, while the GPU has an empty CU for it; it reads
-  // *info's zero and the Gram matrix only after flag 0 is raised behind both.
-  const bool server = h->chain_server && npanel_all <= CHAIN_MAX_PANELS;
-  unsigned *flag_in = h->chain_flags, *flag_out = h->chain_flags + CHAIN_MAX_PANELS;
-  unsigned *flag_err = h->chain_flags + 2 * CHAIN_MAX_PANELS;
-  unsigned epoch = 0;
-  if (server) {
-    epoch = ++h->chain_epoch;
-    if (epoch == 0) epoch = ++h->chain_epoch;  // 0 is the cleared state
-    launch_diag256_server(h->sv, h->bufA, ld, h->bufL, ld, h->Dinv, npanel_all, h->n, h->info,
-                          flag_in, flag_out, flag_err, epoch);
-  }
   // Gram matrix: the first super-panel's block columns on the panel stream -- the chain
   // starts ~30 us later instead of after the whole 0.5 ms build -- the rest on the main stream
   launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld,
@@ -585,12 +555,7 @@ static int factorize(gogp_handle *h, bool eager) {
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
       double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
       // 256x256 diagonal block: factor + dense inverse, one workgroup
-      if (server) {
-        launch_chain_flag_set(sp, flag_in + p, epoch);            // block p has its last update
-        launch_chain_flag_wait(sp, flag_out + p, epoch, flag_err);  // ... and is factored
-      } else {
-        launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
-      }
+      launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
       const int mt2 = (int)((npad - c2) / TILE);
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
       if (mt2 > 0)
@@ -643,18 +608,6 @@ static int factorize(gogp_handle *h, bool eager) {
     if (eager) {
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
       trtri_superstep(h, P0, nsub, st, s2);
-      // Split LAUUM: once the column panels [0, CE) of Y are final, the part of
-      // K^-1 = Y Y^T that only sums k < CE can run (low-priority stream) while both
-      // sweeps wind down.  It writes lower tiles with rows < CE of bufA, which the
-      // Cholesky sweep has finished with (its work area is now rows/cols >= CE).
-      if (h->lauum_split_pct > 0 && h->lauum_ksplit == 0 && CE < npad &&
-          CE * 100 >= npad * (int64_t)h->lauum_split_pct) {
-        (void)hipStreamWaitEvent(h->sl, ev(h, EV_BASE + 4 * P0 + 2), 0);
-        launch_dgemm_nt(h->sl, GEMM_LAUUM, (int)(CE / TILE), (int)(CE / TILE), CE, 1.0, h->bufY, ld,
-                        h->bufY, ld, 0.0, h->bufA, ld, pf);
-        (void)hipEventRecord(ev(h, EV_LAUUM1), h->sl);
-        h->lauum_ksplit = CE;
-      }
     }
   }
   if (eager) {
@@ -666,8 +619,6 @@ static int factorize(gogp_handle *h, bool eager) {
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
-  if (server)
-    HIPCHK(h, hipMemcpyAsync(h->hscal + 9, flag_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
     // triangular inverse is complete (st), instead of 64 dependent substitution steps
@@ -686,18 +637,6 @@ static int factorize(gogp_handle *h, bool eager) {
   h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
-  if (server) {
-    unsigned cerr = 0;
-    memcpy(&cerr, h->hscal + 9, sizeof cerr);
-    if (cerr != 0) {  // a spin limit expired: the chain drained without doing its work
-      for (hipStream_t q : {sp, st, s2, h->sl, h->sv}) (void)hipStreamSynchronize(q);
-      (void)hipMemset(flag_err, 0, sizeof(unsigned));
-      h->alpha_pending = false;
-      h->trtri_done = h->trtri_pending = false;
-      h->lauum_ksplit = 0;
-      return fail(h, GOGP_EHIP, "chain server: a flag wait timed out");
-    }
-  }
   long long info = 0;
   memcpy(&info, h->hscal + 8, sizeof info);
   if (info != 0) {
@@ -705,7 +644,6 @@ static int factorize(gogp_handle *h, bool eager) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s2);
     (void)hipStreamSynchronize(h->sl);
-    h->lauum_ksplit = 0;
     h->alpha_pending = false;
     h->trtri_done = h->trtri_pending = false;
     h->notpd = (int64_t)info - 1;
@@ -773,7 +711,6 @@ static int factorize_dist(gogp_handle *h) {
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
   h->trtri_done = false;
-  h->lauum_ksplit = 0;
   h->notpd = -1;
   int rc = upload_params(h);
   if (rc != GOGP_OK) return rc;
@@ -844,7 +781,7 @@ static int factorize_dist(gogp_handle *h) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
         launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
-                        L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf, 0, 0, &own);
+                        L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf, &own);
       }
       (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // my bulk update of super-step P0 done
     }
@@ -883,7 +820,10 @@ static int compute_kinv_dist(gogp_handle *h) {
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s, sp = h->sp;
   GemmProfile *pf = &h->prof;
-  if (!h->bufY) HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+  {
+    const int rcy = ensure_y(h);
+    if (rcy != GOGP_OK) return rcy;
+  }
   double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
   const int npanel = (int)(npad / PANEL);
   const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
@@ -931,14 +871,14 @@ static int compute_kinv_dist(gogp_handle *h) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
         launch_dgemm_nt(s, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
-                        R + C3, ld, pf, 0, 0, &own);
+                        R + C3, ld, pf, &own);
       }
     }
   }
   // K^-1 = Y Y^T: this rank's tile rows only (ti % G == me)
   const GemmOwn rows = {G, me, 1, 0};
-  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf, 0,
-                  npad, &rows);
+  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf,
+                  &rows);
   h->trtri_done = true;
   h->have_kinv = true;
   return GOGP_OK;
@@ -1066,8 +1006,8 @@ static int compute_kinv(gogp_handle *h) {
   if (!h->trtri_done) {
     // lazy path: the triangular inverse was not fused into the factorisation
     hipStream_t sp = h->lookahead ? h->sp : h->s;
-    if (!h->bufY)
-      HIPCHK(h, hipMalloc(&h->bufY, (size_t)npad * (size_t)npad * sizeof(double)));
+    const int rcy = ensure_y(h);
+    if (rcy != GOGP_OK) return rcy;
     launch_zero_upper_blocks(s, h->bufA, ld, npad);
     order(h, EV_INIT, s, sp);
     const int npanel = (int)(npad / PANEL);
@@ -1079,11 +1019,9 @@ static int compute_kinv(gogp_handle *h) {
     (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
   }
   h->trtri_pending = false;
-  // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over
-  // it.  With a split LAUUM the k < lauum_ksplit part was summed during the sweep.
-  if (h->lauum_ksplit > 0) (void)hipStreamWaitEvent(s, ev(h, EV_LAUUM1), 0);
+  // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
   launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, h->bufY, ld, h->bufY, ld, 0.0,
-                  h->bufA, ld, pf, h->lauum_ksplit, npad);
+                  h->bufA, ld, pf);
   h->have_kinv = true;
   return GOGP_OK;
 }
@@ -1359,15 +1297,6 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     h->eager = value != 0;
     return GOGP_OK;
   }
-  if (strcmp(name, "lauum_split") == 0) {
-    if (value < 0 || value > 95) return fail(h, GOGP_EARG, "lauum_split must be 0..95 (percent)");
-    h->lauum_split_pct = (int)value;
-    return GOGP_OK;
-  }
-  if (strcmp(name, "chain_server") == 0) {
-    h->chain_server = value != 0;
-    return GOGP_OK;
-  }
   if (strcmp(name, "superpanel") == 0) {
     if (value < 1 || value > 8) return fail(h, GOGP_EARG, "superpanel must be 1..8");
     h->superpanel = (int)value;
@@ -1376,131 +1305,3 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   return fail(h, GOGP_EARG, "unknown option");
 }
 
-extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
-                                  double *clock_mhz) {
-  if (!tflops || iters <= 0) return GOGP_EARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
-  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
-  return mfma_f64_peak(iters, tflops, cyc_per_mfma, clock_mhz);
-}
-
-extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
-                                  const double *A, const double *B, double beta, double *C) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GOGP_EARG;
-  if (M % TILE || N % TILE || K % GEMM_BK) return GOGP_EARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
-  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
-  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  hipError_t e = hipMalloc(&dA, (size_t)M * K * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * K * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
-  if (e == hipSuccess) e = hipMemcpy(dA, A, (size_t)M * K * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dB, B, (size_t)N * K * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)M * N * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    launch_dgemm_nt(0, GEMM_RECT, (int)(M / TILE), (int)(N / TILE), K, alpha, dA, K, dB, K, beta,
-                    dC, N, nullptr);
-    e = hipDeviceSynchronize();
-  }
-  if (e == hipSuccess) e = hipMemcpy(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipFree(dA);
-  (void)hipFree(dB);
-  (void)hipFree(dC);
-  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
-}
-
-// Diagnostic: factor+invert one 256x256 SPD block (host buffers) with the stamped
-// build of the diagonal kernel; returns the factor, the inverse and 24 s_memtime stamps.
-namespace gogp {
-void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
-                            long long *info, unsigned long long *stamps);
-}
-extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
-                                 unsigned long long *stamps, double *elapsed_us) {
-  if (!A || !Lout || !Dinv || !stamps) return GOGP_EARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
-  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
-  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
-  long long *dinfo = nullptr;
-  unsigned long long *dst = nullptr;
-  const size_t nb = 256 * 256 * sizeof(double);
-  hipError_t e = hipMalloc(&dA, nb);
-  if (e == hipSuccess) e = hipMalloc(&dL, nb);
-  if (e == hipSuccess) e = hipMalloc(&dD, nb);
-  if (e == hipSuccess) e = hipMalloc(&dinfo, 8);
-  if (e == hipSuccess) e = hipMalloc(&dst, 32 * 8);
-  if (e == hipSuccess) e = hipMemcpy(dA, A, nb, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(dinfo, 0, 8);
-  if (e == hipSuccess) e = hipMemset(dst, 0, 32 * 8);
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  float ms = 0.f;
-  if (e == hipSuccess) {
-    launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);  // warm-up
-    (void)hipDeviceSynchronize();
-    (void)hipEventRecord(e0, 0);
-    launch_diag256(0, dA, 256, dL, 256, dD, 0, 256, dinfo);  // product build, timed
-    (void)hipEventRecord(e1, 0);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);
-    e = hipDeviceSynchronize();
-  }
-  if (e == hipSuccess) e = hipMemcpy(Lout, dL, nb, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(Dinv, dD, nb, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(stamps, dst, 32 * 8, hipMemcpyDeviceToHost);
-  if (elapsed_us) *elapsed_us = ms * 1e3;
-  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dinfo); (void)hipFree(dst);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
-}
-
-// Benchmark hook for the tile kernel: times `reps` launches of one GEMM shape on
-// device-resident pseudo-random operands (lda = ldb = K, ldc = nt*128).
-extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
-                               double *ms_per_launch, double *tflops) {
-  if (mt <= 0 || nt <= 0 || K <= 0 || K % GEMM_BK || reps <= 0 || mode < 0 || mode > 2)
-    return GOGP_EARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
-  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
-  const int64_t M = (int64_t)mt * TILE, N = (int64_t)nt * TILE;
-  const int64_t Kld = (mode == GEMM_LAUUM) ? M : K;  // LAUUM: K range = matrix size
-  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  hipError_t e = hipMalloc(&dA, (size_t)M * Kld * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * Kld * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
-  if (e != hipSuccess) return GOGP_ENOMEM;
-  launch_fill(0, dA, M * Kld, 0.5);
-  launch_fill(0, dB, N * Kld, 0.25);
-  launch_fill(0, dC, M * N, 1.0);
-  GemmProfile pf;
-  pf.on = true;
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
-  for (int w = 0; w < 2; ++w)
-    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, nullptr);
-  (void)hipDeviceSynchronize();
-  (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r)
-    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, &pf);
-  (void)hipEventRecord(e1, 0);
-  e = hipEventSynchronize(e1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  if (ms_per_launch) *ms_per_launch = ms / reps;
-  if (tflops) *tflops = pf.flops / (ms * 1e-3) / 1e12;
-  for (auto ev_ : pf.pool) (void)hipEventDestroy(ev_);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(dA);
-  (void)hipFree(dB);
-  (void)hipFree(dC);
-  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
-}

@@ -60,13 +60,11 @@ enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2,
 
 // C(mt*128 x nt*128) = beta*C + alpha * A * B^T, row-major, K multiple of 16.
 // GEMM_LOWER: square tile grid mt x mt, only tiles ti >= tj.
-// GEMM_LAUUM: lower tiles; tile (ti,tj) sums k over [max(ti*128, kskip), kend) (kend = 0: K)
-// and accumulates into C where its range was cut by kskip (split LAUUM).
+// GEMM_LAUUM: lower tiles; tile (ti,tj) sums k over [ti*128, K).
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
                      double alpha, const double *A, int64_t lda, const double *B,
                      int64_t ldb, double beta, double *C, int64_t ldc,
-                     GemmProfile *prof, int64_t kskip = 0, int64_t kend = 0,
-                     const GemmOwn *own = nullptr);
+                     GemmProfile *prof, const GemmOwn *own = nullptr);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
@@ -99,15 +97,6 @@ void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
-// chain server (diag256.hip): one resident workgroup factors the diagonal blocks 0..npanel-1
-// in order, driven by epoch-valued flags; set / wait are the stream-side ends of the flags
-void launch_diag256_server(hipStream_t s, const double *A, int64_t ld, double *L, int64_t ldl,
-                           double *Dinv, int npanel, int64_t nvalid, long long *info,
-                           const unsigned *flag_in, unsigned *flag_out, unsigned *err,
-                           unsigned epoch);
-void launch_chain_flag_set(hipStream_t s, unsigned *flag, unsigned epoch);
-void launch_chain_flag_wait(hipStream_t s, const unsigned *flag, unsigned epoch, unsigned *err);
-constexpr int CHAIN_MAX_PANELS = 4096;  // N up to 1M
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld);
 void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,
@@ -137,7 +126,5 @@ void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n,
                           double *out);
-
-int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz);
 
 }  // namespace gogp

@@ -19,13 +19,11 @@
 // which hides the barrier / prologue / epilogue bubbles of any one of them.  Mid-size
 // launches use 256 threads = 4 waves of 64x64 (128 acc VGPRs, two waves per SIMD), and
 // the skinny GEMMs of the panel chain a 64x64 tile.  K is walked in steps of 16:
-// both operand tiles (128 rows x 16 doubles = one 128-B line per row) are
-// staged global -> registers -> LDS, double-buffered, one barrier per step.
+// both operand tiles (128 rows x 16 doubles = one 128-B line per row) go
+// global -> LDS directly (global_load_lds_dwordx4), double-buffered, one barrier per step.
 // LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so
 // that the MFMA fragment reads (16 rows x 2 k per 32-lane group, ds_read_b64)
 // hit 32 distinct 8-B bank pairs: conflict-free.
-#include <stdlib.h>
-
 #include <algorithm>
 
 #include "common.h"
@@ -43,9 +41,8 @@ struct GemmArgs {
   int mt, nt;
   int nkt;  // K / 16
   double alpha, beta;
-  // GEMM_LAUUM only: the K range of tile (ti,tj) is [max(ti*BT, kskip), kend); tiles
-  // whose range starts below kskip accumulate (beta = 1), the others overwrite
-  int kskip, kend;
+  // GEMM_LAUUM only: the K range of tile (ti,tj) is [ti*BT, kend)
+  int kend;
   // Ownership filter of a sharded evaluation (own_n <= 1: none).  RECT / LOWER: a tile
   // is computed iff its block column belongs to this rank, i.e.
   // ((own_col0 + tj) / own_tps) % own_n == own_r  (tile columns counted in units of
@@ -75,10 +72,10 @@ __device__ __forceinline__ void wait_vmcnt0() {
 // BT = workgroup tile (128 or 64).  NW = 4: 2x2 waves, each (BT/2)x(BT/2) outputs =
 // MT x MT MFMA tiles, MT = BT/32.  NW = 8 (BT = 128): 2x4 waves, each 64x32 outputs:
 // half the accumulators per wave (<= 128 VGPRs), so four waves fit on a SIMD.
-// DIRECT: operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
 // ds_write): a wave's 64 lanes x 16 B land on 1 KB of consecutive LDS = 8 rows of the tile,
 // so the XOR swizzle is applied on the GLOBAL side (lane (row, pos) fetches chunk pos ^ swz(row)).
-template <int MODE, int BT, int NW, bool DIRECT>
+template <int MODE, int BT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   constexpr int MT = BT / 32;                          // MFMA tiles per wave, rows
   constexpr int NTW = (NW == 8) ? BT / 64 : BT / 32;   // MFMA tiles per wave, columns
@@ -120,13 +117,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     }
   }
   int kbeg = 0, nkt = g.nkt;
-  double beta = g.beta;
+  const double beta = g.beta;
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
-    if (kbeg < g.kskip) {  // second pass of a split LAUUM: [0, kskip) was summed before
-      kbeg = g.kskip;
-      beta = 1.0;
-    }
     nkt = (g.kend - kbeg) / GEMM_BK;
     if (nkt <= 0) return;  // whole-workgroup exit (tile-uniform)
   }
@@ -137,13 +130,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   // ---- staging map: thread -> (row, 16-B chunk), NQ rows per operand --------
   const int srow = tid >> 3;  // 0..SROWS-1, +SROWS*q
   const int schunk = tid & 7;
-  const int gchunk = DIRECT ? (schunk ^ ((srow >> 1) & 7)) : schunk;  // SROWS*q never changes swz
+  const int gchunk = schunk ^ ((srow >> 1) & 7);  // SROWS*q never changes swz
   const double *Ap = Ag + (long)srow * g.lda + gchunk * 2;
   const double *Bp = Bg + (long)srow * g.ldb + gchunk * 2;
   const long a_step = (long)SROWS * g.lda, b_step = (long)SROWS * g.ldb;
-  int soff[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) soff[q] = lds_off(srow + SROWS * q, schunk);
 
   // ---- fragment map --------------------------------------------------------
   const int wr = (NW == 8) ? wid >> 2 : wid >> 1;
@@ -169,19 +159,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   const int coff = (lane >> 4) * (int)g.ldc + (lane & 15);
   const double alpha = g.alpha;
 
-  f64x2 ra[NQ], rb[NQ];
   // prologue loads of k-tile 0 go out first, the C tile right behind them: the
   // accumulators start at (beta/alpha) C, so the epilogue is stores only and the
   // C read latency overlaps the operand pipeline fill
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (DIRECT) {
-      load16_to_lds(Ap + q * a_step, &lds[0][0][(wid * 8 + SROWS * q) * GEMM_BK]);
-      load16_to_lds(Bp + q * b_step, &lds[0][1][(wid * 8 + SROWS * q) * GEMM_BK]);
-    } else {
-      ra[q] = *reinterpret_cast<const f64x2 *>(Ap + q * a_step);
-      rb[q] = *reinterpret_cast<const f64x2 *>(Bp + q * b_step);
-    }
+    load16_to_lds(Ap + q * a_step, &lds[0][0][(wid * 8 + SROWS * q) * GEMM_BK]);
+    load16_to_lds(Bp + q * b_step, &lds[0][1][(wid * 8 + SROWS * q) * GEMM_BK]);
   }
   f64x4 acc[MT][NTW];
   if (beta != 0.0) {
@@ -199,15 +183,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
   }
-  if (!DIRECT) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      *reinterpret_cast<f64x2 *>(&lds[0][0][soff[q]]) = ra[q];
-      *reinterpret_cast<f64x2 *>(&lds[0][1][soff[q]]) = rb[q];
-    }
-  } else {
-    wait_vmcnt0();  // the tile is in LDS
-  }
+  wait_vmcnt0();  // the tile is in LDS
   __syncthreads();
 
   int cur = 0;
@@ -218,14 +194,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
       const double *bp = Bp + (long)(kt + 1) * GEMM_BK;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        if (DIRECT) {
-          // buffer cur^1 was last read in step kt-1; every wave has passed that step's barrier
-          load16_to_lds(ap + q * a_step, &lds[cur ^ 1][0][(wid * 8 + SROWS * q) * GEMM_BK]);
-          load16_to_lds(bp + q * b_step, &lds[cur ^ 1][1][(wid * 8 + SROWS * q) * GEMM_BK]);
-        } else {
-          ra[q] = *reinterpret_cast<const f64x2 *>(ap + q * a_step);
-          rb[q] = *reinterpret_cast<const f64x2 *>(bp + q * b_step);
-        }
+        // buffer cur^1 was last read in step kt-1; every wave has passed that step's barrier
+        load16_to_lds(ap + q * a_step, &lds[cur ^ 1][0][(wid * 8 + SROWS * q) * GEMM_BK]);
+        load16_to_lds(bp + q * b_step, &lds[cur ^ 1][1][(wid * 8 + SROWS * q) * GEMM_BK]);
       }
     }
     const double *la = lds[cur][0];
@@ -243,17 +214,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
         for (int n = 0; n < NTW; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
-    if (more) {
-      if (DIRECT) {
-        wait_vmcnt0();
-      } else {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][0][soff[q]]) = ra[q];
-          *reinterpret_cast<f64x2 *>(&lds[cur ^ 1][1][soff[q]]) = rb[q];
-        }
-      }
-    }
+    if (more) wait_vmcnt0();
     __syncthreads();
     cur ^= 1;
   }
@@ -268,24 +229,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
         (Cg + (long)(m * 16 + 4 * v) * g.ldc)[coff + n * 16] = alpha * acc[m][n][v];
 }
 
-// GOGP_GEMM_W8 = 0 / 1 forces the 4-wave / 8-wave 128-tile kernel (A/B measurements);
-// unset: 8 waves for the large launches, where they measured 4-9% faster.
-// GOGP_GEMM_DIRECT=0 selects the register-staged operand path (A/B measurements); default:
-// global -> LDS direct loads (+3-4 % on the large GEMMs, -2.3 % time per evaluation).
-static const bool g_gemm_direct = [] {
-  const char *e = getenv("GOGP_GEMM_DIRECT");
-  return !e || atoi(e) != 0;
-}();
-
-static const int g_gemm_w8 = [] {
-  const char *e = getenv("GOGP_GEMM_W8");
-  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-}();
-
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
                      const double *A, int64_t lda, const double *B, int64_t ldb,
-                     double beta, double *C, int64_t ldc, GemmProfile *prof, int64_t kskip,
-                     int64_t kend, const GemmOwn *own) {
+                     double beta, double *C, int64_t ldc, GemmProfile *prof, const GemmOwn *own) {
   if (mt <= 0 || nt <= 0 || K <= 0) return;
   GemmArgs g;
   g.A = A;
@@ -299,9 +245,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.nkt = (int)(K / GEMM_BK);
   g.alpha = alpha;
   g.beta = beta;
-  if (kend <= 0 || kend > K) kend = K;
-  g.kskip = (int)kskip;
-  g.kend = (int)kend;
+  g.kend = (int)K;
   g.own_n = own ? own->n : 0;
   g.own_r = own ? own->r : 0;
   g.own_tps = own ? own->tiles_per_sp : 1;
@@ -324,10 +268,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
       flops = 2.0 * (double)ntiles * TILE * TILE * (double)K;
     } else {
       flops = 0;
-      for (int i = 0; i < mt; ++i) {
-        const int64_t kb = std::max<int64_t>((int64_t)i * TILE, kskip);
-        if (kend > kb) flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(kend - kb);
-      }
+      for (int i = 0; i < mt; ++i)
+        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - (int64_t)i * TILE);
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -345,155 +287,35 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   }
   // Small launches (the skinny GEMMs of the panel chain) use 64x64 tiles: 4x the
   // workgroups and a quarter of the per-tile latency.  LAUUM keeps 128 (its K
-  // ranges are cut at 128-row granularity).
-  static const int small_limit = getenv("GOGP_SMALL_TILES") ? atoi(getenv("GOGP_SMALL_TILES")) : 384;
-  const bool small = (mode != GEMM_LAUUM) && (ntiles < small_limit);
-  dim3 block(256);
+  // ranges are cut at 128-row granularity).  Launches of >= 3072 tiles and LAUUM use the
+  // 8-wave shape of the 128x128 tile (measured 4-9 % faster there), the rest the 4-wave one.
+  const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
   if (small) {
     g.mt = mt * 2;
     g.nt = nt * 2;
     g.own_tps *= 2;  // ownership counted in 64-wide tile columns
     g.own_col0 *= 2;
     const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
-    dim3 grid(n64);
-    if (mode == GEMM_RECT) {
-      if (g_gemm_direct)
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4, true>), grid, block, 0, s, g);
-      else
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4, false>), grid, block, 0, s, g);
-    } else {
-      if (g_gemm_direct)
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4, true>), grid, block, 0, s, g);
-      else
-        hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4, false>), grid, block, 0, s, g);
-    }
-  } else if (g_gemm_w8 == 1 || (g_gemm_w8 < 0 && (mode == GEMM_LAUUM || ntiles >= 3072))) {
-    dim3 grid(ntiles), block8(512);
-    switch (mode) {
-      case GEMM_RECT:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8, true>), grid, block8, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8, false>), grid, block8, 0, s, g);
-        break;
-      case GEMM_LOWER:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8, true>), grid, block8, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8, false>), grid, block8, 0, s, g);
-        break;
-      case GEMM_LAUUM:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8, true>), grid, block8, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8, false>), grid, block8, 0, s, g);
-        break;
-      default:
-        break;
-    }
+    if (mode == GEMM_RECT)
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4>), dim3(n64), dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 64, 4>), dim3(n64), dim3(256), 0, s, g);
+  } else if (mode == GEMM_LAUUM || ntiles >= 3072) {
+    const dim3 grid(ntiles), block8(512);
+    if (mode == GEMM_RECT)
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 8>), grid, block8, 0, s, g);
+    else if (mode == GEMM_LOWER)
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 8>), grid, block8, 0, s, g);
+    else
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 8>), grid, block8, 0, s, g);
   } else {
-    dim3 grid(ntiles);
-    switch (mode) {
-      case GEMM_RECT:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4, true>), grid, block, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4, false>), grid, block, 0, s, g);
-        break;
-      case GEMM_LOWER:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4, true>), grid, block, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4, false>), grid, block, 0, s, g);
-        break;
-      case GEMM_LAUUM:
-        if (g_gemm_direct)
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, true>), grid, block, 0, s, g);
-        else
-          hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LAUUM, 128, 4, false>), grid, block, 0, s, g);
-        break;
-      default:
-        break;
-    }
+    const dim3 grid(ntiles), block(256);
+    if (mode == GEMM_RECT)
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 128, 4>), grid, block, 0, s, g);
+    else
+      hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_LOWER, 128, 4>), grid, block, 0, s, g);
   }
   if (e1) (void)hipEventRecord(e1, s);
-}
-
-// ---- fp64 MFMA issue-rate microbenchmark (roofline calibration) -------------
-// 8 independent accumulators held in AGPRs by inline asm (the builtin form makes
-// hipcc shuttle loop-carried accumulators between VGPRs and AGPRs every
-// iteration, which under-reads the rate).  Wave 0 of block 0 also reports shader
-// cycles (s_memtime) and wall ticks (s_memrealtime, 100 MHz) around its loop.
-__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *sink,
-                                                            unsigned long long *clk) {
-  f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
-  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-  unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-  int cnt = iters;
-  // the whole loop lives in one asm statement so that the accumulators stay in
-  // AGPRs across iterations
-  asm volatile(
-      "1:\n\t"
-      "v_mfma_f64_16x16x4_f64 %0, %9, %10, %0\n\t"
-      "v_mfma_f64_16x16x4_f64 %1, %9, %10, %1\n\t"
-      "v_mfma_f64_16x16x4_f64 %2, %9, %10, %2\n\t"
-      "v_mfma_f64_16x16x4_f64 %3, %9, %10, %3\n\t"
-      "v_mfma_f64_16x16x4_f64 %4, %9, %10, %4\n\t"
-      "v_mfma_f64_16x16x4_f64 %5, %9, %10, %5\n\t"
-      "v_mfma_f64_16x16x4_f64 %6, %9, %10, %6\n\t"
-      "v_mfma_f64_16x16x4_f64 %7, %9, %10, %7\n\t"
-      "s_sub_u32 %8, %8, 1\n\t"
-      "s_cmp_lg_u32 %8, 0\n\t"
-      "s_cbranch_scc1 1b"
-      : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7),
-        "+s"(cnt)
-      : "v"(a), "v"(b)
-      : "scc");
-  unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-  double s = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
-  if (s == 12345.678) sink[0] = s;  // keep the chains live
-  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
-    clk[0] = t1 - t0;
-    clk[1] = r1 - r0;
-  }
-}
-
-// tflops: achieved rate with every SIMD issuing; cyc_per_mfma / clock_mhz from wave 0.
-int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz) {
-  double *sink = nullptr;
-  unsigned long long *clk = nullptr;
-  if (hipMalloc(&sink, 8) != hipSuccess) return GOGP_EHIP;
-  if (hipMalloc(&clk, 16) != hipSuccess) return GOGP_EHIP;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GOGP_EHIP;
-  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters / 4 + 1, sink,
-                     (unsigned long long *)nullptr);  // warm-up (clock ramp)
-  (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink, clk);
-  (void)hipEventRecord(e1, 0);
-  if (hipEventSynchronize(e1) != hipSuccess) return GOGP_EHIP;
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
-  *tflops = flops / (ms * 1e-3) / 1e12;
-  unsigned long long h[2] = {0, 0};
-  (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-  // two waves share a SIMD: cycles per MFMA issued on that SIMD
-  if (cyc_per_mfma) *cyc_per_mfma = (double)h[0] / ((double)iters * 8.0 * 2.0);
-  if (clock_mhz) *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(sink);
-  (void)hipFree(clk);
-  return GOGP_OK;
 }
 
 }  // namespace gogp

@@ -36,7 +36,15 @@
 // inverse phases, the double-buffered B chunks during the products.
 #include "common.h"
 
-namespace gogp {
+// The test-hook library compiles this file a second time into its own namespace
+// (-DGOGP_NS=gogp_th -DGOGP_BUILD_TESTHOOKS) to get the stamped diagnostic build of the
+// kernel without putting it into libgogp_hip.so.
+#ifndef GOGP_NS
+#define GOGP_NS gogp
+#endif
+namespace GOGP_NS {
+using namespace gogp;
+
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -590,76 +598,6 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
   diag256_body<DO_POTRF, STAMP>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, stamps);
 }
 
-// ---- chain server ------------------------------------------------------------------------
-// The diagonal kernel needs a whole CU (152 KB of LDS), and while the tile kernels of the
-// other streams keep every CU half full it waits for one to drain: 280 us on average per
-// panel at N = 16384, more than its own 230 us (profiles/).  The server is ONE
-// workgroup that stays resident for a whole factorisation and does the diagonal blocks
-// p = 0 .. npanel-1 in order: it spins on flag_in[p] (set by a one-thread kernel on the panel
-// stream once block p has its last update), factors and inverts the block, and releases
-// flag_out[p], which a one-wave kernel on the panel stream waits for before the panel solve.
-// Flags carry the epoch of the factorisation, so they never need clearing.  Cross-kernel
-// visibility: producers finish (kernel-end release) before the set kernel runs; the server
-// acquires at agent scope (invalidates its L1 / XCD L2) before reading the block and
-// releases at agent scope (writes its L2 back) before raising flag_out.  Every spin has a
-// wall-clock limit (s_memrealtime, 100 MHz): on expiry it raises *err and the server and all
-// waiters drain, so a protocol error cannot hang the GPU.
-// Measured at N = 16384: per-block latency 267 us steady (was 510 us mean), tile-kernel idle
-// gaps 5.6 -> 2.3 ms per evaluation, but the same 83 ms per evaluation: the sweep is bound by
-// the tile kernel's aggregate throughput, not by this chain.  Hence an option
-// (gogp_set_option "chain_server"), off by default.
-constexpr unsigned long long SPIN_LIMIT_TICKS = 20ull * 100000000ull;  // 20 s
-
-__device__ __forceinline__ bool spin_until(const unsigned *flag, unsigned epoch, unsigned *err) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-    __builtin_amdgcn_s_sleep(4);
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-  }
-  return true;
-}
-
-__global__ __launch_bounds__(NT) void diag256_server_kernel(const double *__restrict__ A, long ld,
-                                                              double *__restrict__ L, long ldl,
-                                                              double *__restrict__ Dinv, int npanel,
-                                                              long nvalid, long long *info,
-                                                              const unsigned *flag_in,
-                                                              unsigned *flag_out, unsigned *err,
-                                                              unsigned epoch) {
-  __shared__ __attribute__((aligned(16))) double S[128 * SLD];
-  __shared__ __attribute__((aligned(16))) double G[GSIZE];
-  __shared__ double rinv_s[8 * 16];
-  __shared__ int go;
-#pragma unroll 1
-  for (int p = 0; p < npanel; ++p) {
-    if (threadIdx.x == 0) go = spin_until(flag_in + p, epoch, err) ? 1 : 0;
-    __syncthreads();
-    if (!__builtin_amdgcn_readfirstlane(go)) break;  // workgroup-uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const long c0 = (long)p * 256;
-    diag256_body<true, false>(S, G, rinv_s, A + c0 * ld + c0, ld, L + c0 * ldl + c0, ldl,
-                              Dinv + (long)p * 256 * 256, c0, nvalid, info, nullptr);
-    __syncthreads();  // all stores of the block issued and complete (workgroup release)
-    if (threadIdx.x == 0)
-      __hip_atomic_store(flag_out + p, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-__global__ void chain_flag_set_kernel(unsigned *flag, unsigned epoch) {
-  __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void chain_flag_wait_kernel(const unsigned *flag, unsigned epoch, unsigned *err) {
-  if (threadIdx.x == 0) {
-    (void)spin_until(flag, epoch, err);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
   hipLaunchKernelGGL((diag256_kernel<true, false>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
@@ -673,27 +611,13 @@ void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double 
                      (unsigned long long *)nullptr);
 }
 
-void launch_diag256_server(hipStream_t s, const double *A, int64_t ld, double *L, int64_t ldl,
-                           double *Dinv, int npanel, int64_t nvalid, long long *info,
-                           const unsigned *flag_in, unsigned *flag_out, unsigned *err,
-                           unsigned epoch) {
-  hipLaunchKernelGGL(diag256_server_kernel, dim3(1), dim3(NT), 0, s, A, (long)ld, L, (long)ldl, Dinv,
-                     npanel, (long)nvalid, info, flag_in, flag_out, err, epoch);
-}
-
-void launch_chain_flag_set(hipStream_t s, unsigned *flag, unsigned epoch) {
-  hipLaunchKernelGGL(chain_flag_set_kernel, dim3(1), dim3(1), 0, s, flag, epoch);
-}
-
-void launch_chain_flag_wait(hipStream_t s, const unsigned *flag, unsigned epoch, unsigned *err) {
-  hipLaunchKernelGGL(chain_flag_wait_kernel, dim3(1), dim3(64), 0, s, flag, epoch, err);
-}
-
+#ifdef GOGP_BUILD_TESTHOOKS
 // diagnostic: run the stamped build once on a device-resident 256x256 block
 void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
                             long long *info, unsigned long long *stamps) {
   hipLaunchKernelGGL((diag256_kernel<true, true>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
                      Dinv, 0L, 256L, info, stamps);
 }
+#endif
 
-}  // namespace gogp
+}  // namespace GOGP_NS

@@ -1,0 +1,224 @@
+// testhooks.hip -- measurement / diagnostic entry points (include/gogp_testhooks.h).
+// Built into gogp_amd/libgogp_testhooks.so, which links libgogp_hip.so and calls its
+// internal launchers; none of this is part of the product ABI (include/gogp_hip.h).
+#include <stdio.h>
+
+#include "common.h"
+#include "../../include/gogp_testhooks.h"
+
+namespace gogp_th {
+void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                    double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
+                            long long *info, unsigned long long *stamps);
+}
+
+namespace gogp {
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---- fp64 MFMA issue-rate microbenchmark (roofline calibration) -------------
+// 8 independent accumulators held in AGPRs by inline asm (the builtin form makes
+// hipcc shuttle loop-carried accumulators between VGPRs and AGPRs every
+// iteration, which under-reads the rate).  Wave 0 of block 0 also reports shader
+// cycles (s_memtime) and wall ticks (s_memrealtime, 100 MHz) around its loop.
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *sink,
+                                                            unsigned long long *clk) {
+  f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  int cnt = iters;
+  // the whole loop lives in one asm statement so that the accumulators stay in
+  // AGPRs across iterations
+  asm volatile(
+      "1:\n\t"
+      "v_mfma_f64_16x16x4_f64 %0, %9, %10, %0\n\t"
+      "v_mfma_f64_16x16x4_f64 %1, %9, %10, %1\n\t"
+      "v_mfma_f64_16x16x4_f64 %2, %9, %10, %2\n\t"
+      "v_mfma_f64_16x16x4_f64 %3, %9, %10, %3\n\t"
+      "v_mfma_f64_16x16x4_f64 %4, %9, %10, %4\n\t"
+      "v_mfma_f64_16x16x4_f64 %5, %9, %10, %5\n\t"
+      "v_mfma_f64_16x16x4_f64 %6, %9, %10, %6\n\t"
+      "v_mfma_f64_16x16x4_f64 %7, %9, %10, %7\n\t"
+      "s_sub_u32 %8, %8, 1\n\t"
+      "s_cmp_lg_u32 %8, 0\n\t"
+      "s_cbranch_scc1 1b"
+      : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7),
+        "+s"(cnt)
+      : "v"(a), "v"(b)
+      : "scc");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  double s = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+  if (s == 12345.678) sink[0] = s;  // keep the chains live
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
+// tflops: achieved rate with every SIMD issuing; cyc_per_mfma / clock_mhz from wave 0.
+int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz) {
+  double *sink = nullptr;
+  unsigned long long *clk = nullptr;
+  if (hipMalloc(&sink, 8) != hipSuccess) return GOGP_EHIP;
+  if (hipMalloc(&clk, 16) != hipSuccess) return GOGP_EHIP;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GOGP_EHIP;
+  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters / 4 + 1, sink,
+                     (unsigned long long *)nullptr);  // warm-up (clock ramp)
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink, clk);
+  (void)hipEventRecord(e1, 0);
+  if (hipEventSynchronize(e1) != hipSuccess) return GOGP_EHIP;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  unsigned long long h[2] = {0, 0};
+  (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  // two waves share a SIMD: cycles per MFMA issued on that SIMD
+  if (cyc_per_mfma) *cyc_per_mfma = (double)h[0] / ((double)iters * 8.0 * 2.0);
+  if (clock_mhz) *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  (void)hipFree(clk);
+  return GOGP_OK;
+}
+
+
+}  // namespace gogp
+
+using namespace gogp;
+
+extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                                  double *clock_mhz) {
+  if (!tflops || iters <= 0) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  return mfma_f64_peak(iters, tflops, cyc_per_mfma, clock_mhz);
+}
+
+extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
+                                  const double *A, const double *B, double beta, double *C) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return GOGP_EARG;
+  if (M % TILE || N % TILE || K % GEMM_BK) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipError_t e = hipMalloc(&dA, (size_t)M * K * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * K * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(dA, A, (size_t)M * K * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dB, B, (size_t)N * K * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)M * N * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_dgemm_nt(0, GEMM_RECT, (int)(M / TILE), (int)(N / TILE), K, alpha, dA, K, dB, K, beta,
+                    dC, N, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
+// Diagnostic: factor+invert one 256x256 SPD block (host buffers) with the stamped
+// build of the diagonal kernel; returns the factor, the inverse and 24 s_memtime stamps.
+extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
+                                 unsigned long long *stamps, double *elapsed_us) {
+  if (!A || !Lout || !Dinv || !stamps) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *dA = nullptr, *dL = nullptr, *dD = nullptr;
+  long long *dinfo = nullptr;
+  unsigned long long *dst = nullptr;
+  const size_t nb = 256 * 256 * sizeof(double);
+  hipError_t e = hipMalloc(&dA, nb);
+  if (e == hipSuccess) e = hipMalloc(&dL, nb);
+  if (e == hipSuccess) e = hipMalloc(&dD, nb);
+  if (e == hipSuccess) e = hipMalloc(&dinfo, 8);
+  if (e == hipSuccess) e = hipMalloc(&dst, 32 * 8);
+  if (e == hipSuccess) e = hipMemcpy(dA, A, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dinfo, 0, 8);
+  if (e == hipSuccess) e = hipMemset(dst, 0, 32 * 8);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    gogp_th::launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);  // warm-up
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    gogp::launch_diag256(0, dA, 256, dL, 256, dD, 0, 256, dinfo);  // product build, timed
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    gogp_th::launch_diag256_stamped(0, dA, dL, dD, dinfo, dst);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(Lout, dL, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(Dinv, dD, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(stamps, dst, 32 * 8, hipMemcpyDeviceToHost);
+  if (elapsed_us) *elapsed_us = ms * 1e3;
+  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dinfo); (void)hipFree(dst);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
+// Benchmark hook for the tile kernel: times `reps` launches of one GEMM shape on
+// device-resident pseudo-random operands (lda = ldb = K, ldc = nt*128).
+extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
+                               double *ms_per_launch, double *tflops) {
+  if (mt <= 0 || nt <= 0 || K <= 0 || K % GEMM_BK || reps <= 0 || mode < 0 || mode > 2)
+    return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  const int64_t M = (int64_t)mt * TILE, N = (int64_t)nt * TILE;
+  const int64_t Kld = (mode == GEMM_LAUUM) ? M : K;  // LAUUM: K range = matrix size
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipError_t e = hipMalloc(&dA, (size_t)M * Kld * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dB, (size_t)N * Kld * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dC, (size_t)M * N * sizeof(double));
+  if (e != hipSuccess) return GOGP_ENOMEM;
+  launch_fill(0, dA, M * Kld, 0.5);
+  launch_fill(0, dB, N * Kld, 0.25);
+  launch_fill(0, dC, M * N, 1.0);
+  GemmProfile pf;
+  pf.on = true;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
+  for (int w = 0; w < 2; ++w)
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, nullptr);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r)
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, &pf);
+  (void)hipEventRecord(e1, 0);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_launch) *ms_per_launch = ms / reps;
+  if (tflops) *tflops = pf.flops / (ms * 1e-3) / 1e12;
+  for (auto ev_ : pf.pool) (void)hipEventDestroy(ev_);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}

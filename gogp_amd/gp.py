@@ -188,12 +188,12 @@ class GP:
             if n * (self.NDim + 1) != rest:
                 raise ValueError("len(x)")  # gp/gp.go:398-400 panic("len(x)")
             rc = L.gogp_observe_full(self._h, _dp(xa), xa.size, ctypes.byref(lml))
-            if rc == _lib.GOGP_OK:
-                # gp/gp.go:391-396: X, Y are re-sliced from x
-                self._X = xa[P:P + n * self.NDim].reshape(n, self.NDim).copy()
-                self._Y = xa[P + n * self.NDim:].copy()
-                self._data_dirty = False
-                self._with_obs = True
+            # gp/gp.go:391-396: X, Y are re-sliced from x -- also when the factorisation then
+            # fails (the reference panics after the assignment): the device holds these data now
+            self._X = xa[P:P + n * self.NDim].reshape(n, self.NDim).copy()
+            self._Y = xa[P + n * self.NDim:].copy()
+            self._data_dirty = rc != _lib.GOGP_OK  # after a failure: re-upload before the next call
+            self._with_obs = rc == _lib.GOGP_OK
         self._check(rc)
         theta = np.exp(xa[:P])
         self.ThetaSimil = list(theta[:self._ns])  # gp/gp.go:384-385
@@ -276,7 +276,7 @@ def mfma_f64_peak(iters: int = 20000, device: int = -1, details: bool = False):
     """fp64 MFMA issue-rate microbenchmark used to calibrate the roofline:
     TFLOP/s, or (TFLOP/s, cycles per MFMA on one SIMD, shader clock MHz)."""
     v, c, m = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-    rc = _lib.lib().gogp_mfma_f64_peak(device, iters, ctypes.byref(v), ctypes.byref(c),
+    rc = _lib.hooks().gogp_mfma_f64_peak(device, iters, ctypes.byref(v), ctypes.byref(c),
                                        ctypes.byref(m))
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "mfma_f64_peak")
@@ -290,7 +290,7 @@ def dgemm_nt_check(A: np.ndarray, B: np.ndarray, C: np.ndarray, alpha=1.0, beta=
     out = _arr(C).copy()
     M, K = A.shape
     N = B.shape[0]
-    rc = _lib.lib().gogp_test_dgemm_nt(device, M, N, K, alpha, _dp(A), _dp(B), beta, _dp(out))
+    rc = _lib.hooks().gogp_test_dgemm_nt(device, M, N, K, alpha, _dp(A), _dp(B), beta, _dp(out))
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "test_dgemm_nt")
     return out
@@ -304,7 +304,7 @@ def diag256_check(A: np.ndarray, device: int = -1):
     L, X = np.zeros((256, 256)), np.zeros((256, 256))
     st = (ctypes.c_uint64 * 32)()
     us = ctypes.c_double(0.0)
-    rc = _lib.lib().gogp_test_diag256(device, _dp(A), _dp(L), _dp(X), st, ctypes.byref(us))
+    rc = _lib.hooks().gogp_test_diag256(device, _dp(A), _dp(L), _dp(X), st, ctypes.byref(us))
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "test_diag256")
     return L, X, np.array(list(st), dtype=np.uint64), us.value
@@ -313,7 +313,7 @@ def diag256_check(A: np.ndarray, device: int = -1):
 def bench_gemm(mode: int, mt: int, nt: int, K: int, reps: int = 5, device: int = -1):
     """Time the tile kernel on one shape: returns (ms per launch, TFLOP/s)."""
     ms, tf = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    rc = _lib.lib().gogp_bench_gemm(device, mode, mt, nt, K, reps, ctypes.byref(ms), ctypes.byref(tf))
+    rc = _lib.hooks().gogp_bench_gemm(device, mode, mt, nt, K, reps, ctypes.byref(ms), ctypes.byref(tf))
     if rc != _lib.GOGP_OK:
         raise GogpError(rc, "bench_gemm")
     return ms.value, tf.value

@@ -47,6 +47,14 @@ def func_grad(m):
     return f, g
 
 
+def _is_not_positive_definite(e: Exception) -> bool:
+    if isinstance(e, (np.linalg.LinAlgError, ArithmeticError)):
+        return True
+    if getattr(e, "code", None) == 2:  # GOGP_ENOTPD (gp.FactorizeError)
+        return True
+    return type(e).__name__ in ("FactorizeError", "NotPositiveDefinite")
+
+
 def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
           history_size: int = 10, max_step_log: float = 2.0,
           callback: Optional[Callable[[int, np.ndarray, float], None]] = None) -> Result:
@@ -63,7 +71,12 @@ def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
         evals += 1
         try:
             v = m.Observe(xx)
-        except Exception:  # not positive definite etc.: treat as +inf objective
+        except Exception as e:
+            # Only "K is not positive definite at this trial point" (gp/gp.go:228-230) is an
+            # infeasible point the line search may back off from; anything else (a HIP error,
+            # a bad argument) is a real failure and must surface.
+            if not _is_not_positive_definite(e):
+                raise
             return np.inf, None
         if not np.isfinite(v):
             return np.inf, None

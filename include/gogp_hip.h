@@ -225,42 +225,11 @@ int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
  *   "eager"        1 | 0   Observe also runs the triangular inverse (gradient preparation)
  *                          behind the Cholesky sweep / Gradient computes it lazily  (default 1)
  *   "superpanel"   1..8    256-wide panels per trailing update (K = 256 * value)    (default 2)
- *   "lauum_split"  0..95   percent of N whose part of K^-1 = Y Y^T is summed during the
- *                          sweep's tail; 0 = off                                    (default 0)
- *   "chain_server" 0 | 1   diagonal blocks factored by one resident workgroup driven by flags
- *                          instead of one launch per block                          (default 0)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 
 /* Library build info: "gogp_hip <version> gfx950 ..." */
 const char *gogp_version(void);
-
-/* Micro-benchmark used to calibrate the fp64 MFMA roofline: every SIMD issues
- * `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64 from two waves; returns the
- * achieved TFLOP/s and (optionally) the shader cycles per MFMA on one SIMD and
- * the shader clock in MHz observed by one wave during the run. */
-int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
-                       double *clock_mhz);
-
-/* Stand-alone fp64 GEMM test hook: C(MxN,row-major) = beta*C + alpha*A(MxK)*B(NxK)^T
- * on host buffers (copied to the device and back); M,N multiples of 128,
- * K multiple of 16.  Exists so the tile kernel can be parity-tested in
- * isolation against a host reference. */
-int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
-                       const double *A, const double *B, double beta, double *C);
-
-/* Benchmark hook for the tile kernel: `reps` launches of one shape (mode 0 RECT
- * mt x nt tiles, 1 LOWER mt x mt, 2 LAUUM mt x mt with K = mt*128) on device
- * buffers; returns ms per launch and TFLOP/s on the flops launched. */
-int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
-                    double *ms_per_launch, double *tflops);
-
-/* Diagnostic hook for the diagonal-block kernel: factor + invert one 256x256 SPD
- * block given on the host (row-major, lower triangle used); returns the factor,
- * its dense inverse, 24 in-kernel s_memtime stamps of a diagnostic build and the
- * HIP-event time (us) of the product build. */
-int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
-                      unsigned long long *stamps, double *elapsed_us);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,48 @@
+/*
+ * gogp_testhooks.h -- measurement and diagnostic entry points of
+ * gogp_amd/libgogp_testhooks.so (tests/, tools/ and bench.py's roofline calibration).
+ *
+ * NOT part of the drop-in boundary: the product library libgogp_hip.so
+ * (include/gogp_hip.h) does not export these.  The hook library links the product
+ * library and drives its internal launchers.
+ */
+#ifndef GOGP_TESTHOOKS_H
+#define GOGP_TESTHOOKS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Micro-benchmark used to calibrate the fp64 MFMA roofline: every SIMD issues
+ * `iters` x 8 back-to-back v_mfma_f64_16x16x4_f64 from two waves; returns the
+ * achieved TFLOP/s and (optionally) the shader cycles per MFMA on one SIMD and
+ * the shader clock in MHz observed by one wave during the run. */
+int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                       double *clock_mhz);
+
+/* Stand-alone fp64 GEMM test hook: C(MxN,row-major) = beta*C + alpha*A(MxK)*B(NxK)^T
+ * on host buffers (copied to the device and back); M,N multiples of 128,
+ * K multiple of 16.  Exists so the tile kernel can be parity-tested in
+ * isolation against a host reference. */
+int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
+                       const double *A, const double *B, double beta, double *C);
+
+/* Benchmark hook for the tile kernel: `reps` launches of one shape (mode 0 RECT
+ * mt x nt tiles, 1 LOWER mt x mt, 2 LAUUM mt x mt with K = mt*128) on device
+ * buffers; returns ms per launch and TFLOP/s on the flops launched. */
+int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
+                    double *ms_per_launch, double *tflops);
+
+/* Diagnostic hook for the diagonal-block kernel: factor + invert one 256x256 SPD
+ * block given on the host (row-major, lower triangle used); returns the factor,
+ * its dense inverse, 24 in-kernel s_memtime stamps of a diagnostic build and the
+ * HIP-event time (us) of the product build. */
+int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
+                      unsigned long long *stamps, double *elapsed_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOGP_TESTHOOKS_H */

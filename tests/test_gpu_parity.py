@@ -444,12 +444,11 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
 @pytest.mark.parametrize("opts", [
     {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"superpanel": 4}, {"superpanel": 8},
     {"superpanel": 6, "eager": 0},
-    {"chain_server": 1, "eager": 0}, {"lauum_split": 50}, {"lookahead": 0, "superpanel": 4},
+    {"lookahead": 0, "superpanel": 4},
 ], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("n", [300, 2300])
 def test_schedule_options_same_results(gpmod, opts, n):
-    """Every scheduling option (stream layout, super-panel width, lazy inverse, chain server,
-    split LAUUM) computes the same numbers as the default schedule; only the grouping of the
+    """Every scheduling option (stream layout, super-panel width, lazy inverse) computes the same numbers as the default schedule; only the grouping of the
     rank-k updates -- hence rounding -- may differ."""
     rng = np.random.default_rng(n)
     D = 3
@@ -471,30 +470,6 @@ def test_schedule_options_same_results(gpmod, opts, n):
         np.testing.assert_allclose(sg, sg0, rtol=1e-8, atol=1e-11)
     g.close()
     ref.close()
-
-
-def test_chain_server_option_same_results(gpmod):
-    """The resident chain server (one persistent workgroup factoring the diagonal blocks,
-    flag-driven) gives bit-identical results to one launch per block."""
-    rng = np.random.default_rng(5)
-    n, D = 1800, 3
-    X, y = _data(rng, n, D)
-    x = np.log([1.1, 0.5, 0.2])
-    out = []
-    for mode in (0, 1, 1):
-        g = gpmod.GP(D, kernel.Scaled(kernel.Matern32), kernel.UniformNoise, X=X, Y=y)
-        g.set_option("chain_server", mode)
-        lml = g.Observe(x)
-        grad = g.Gradient()
-        lml2 = g.Observe(x + 0.01)  # second factorisation on the same handle: next epoch
-        mu, sigma = g.Produce(X[:7])
-        out.append((lml, grad, lml2, mu, sigma))
-        g.close()
-    for o in out[1:]:
-        assert o[0] == out[0][0] and o[2] == out[0][2]
-        np.testing.assert_array_equal(o[1], out[0][1])
-        np.testing.assert_array_equal(o[3], out[0][3])
-        np.testing.assert_array_equal(o[4], out[0][4])
 
 
 def test_later_handles_as_fast_as_the_first(gpmod):
@@ -639,6 +614,31 @@ def test_handle_reuse_across_sizes_and_call_orders(gpmod):
             g.Gradient()
         mu, sig = g.Produce(Z)
         np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+
+
+def test_absorb_big_then_observe_small_then_big(gpmod):
+    """Regression (round-1 advisor finding): Absorb of a big data set sizes the N-dependent
+    buffers without Y = L^-T; an Observe on small data then allocates Y; going back to the big
+    data must not reuse that small Y with the big leading dimension."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(47)
+    D = 2
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    Xb, yb = _data(rng, 1300, D)
+    Xs, ys = _data(rng, 200, D)
+    x = np.log([1.1, 0.45, 0.25])
+    g = gpmod.GP(D, simil, noise)
+    g.ThetaSimil, g.ThetaNoise = list(np.exp(x[:2])), list(np.exp(x[2:]))
+    g.Absorb(Xb, yb)
+    o = FastOracle(D, simil, noise)
+    for X, y in ((Xs, ys), (Xb, yb), (Xs, ys), (Xb, yb)):
+        g.X, g.Y = X, y
+        o.set_data(X, y)
+        lml_o, grad_o = o.Observe(x), o.Gradient()
+        assert abs(g.Observe(x) - lml_o) <= 1e-8 * abs(lml_o)
+        assert np.abs(g.Gradient() - grad_o).max() <= 1e-6 * max(1.0, np.abs(grad_o).max())
+        np.testing.assert_allclose(g.Alpha, o.Alpha, rtol=1e-6, atol=1e-8)
+    g.close()
 
 
 def test_lazy_and_eager_paths_agree_bitwise_on_lml(gpmod):

@@ -31,6 +31,15 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name)
     assert lib.gogp_version().decode().startswith("gogp_hip")
+    # the product library exports none of the measurement hooks; they live in their own library
+    hk = open(os.path.join(ROOT, "include", "gogp_testhooks.h")).read()
+    hk = re.sub(r"/\*.*?\*/", "", hk, flags=re.S)
+    hooks_declared = set(re.findall(r"\b(gogp_[a-z0-9_]+)\s*\(", hk))
+    assert hooks_declared == {name for name, _, _ in _lib.HOOK_SYMBOLS}
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in hooks_declared:
+        assert not hasattr(raw, name), name
+        assert hasattr(_lib.hooks(), name)
 
 
 def test_descriptor_struct_layout_matches_header(lib):
@@ -98,7 +107,7 @@ def test_no_gpu_fails_loudly(lib):
         gp.GP(1, kernel.Normal)
     assert ei.value.code == _lib.GOGP_EHIP
     v = ctypes.c_double()
-    assert lib.gogp_mfma_f64_peak(0, 10, ctypes.byref(v), None, None) == _lib.GOGP_EHIP
+    assert _lib.hooks().gogp_mfma_f64_peak(0, 10, ctypes.byref(v), None, None) == _lib.GOGP_EHIP
 
 
 def test_product_does_not_import_oracle():

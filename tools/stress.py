@@ -11,8 +11,8 @@ from oracle.oracle import FastOracle
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + seconds
-OPTS = [{}, {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"chain_server": 1},
-        {"lauum_split": 60}, {"superpanel": 4, "eager": 0}]
+OPTS = [{}, {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3},
+        {"superpanel": 4, "eager": 0}]
 nrun = 0
 worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
 while time.time() < t_end:
