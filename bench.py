@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: GP.Observe + GP.Gradient evaluations per second.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one hyperparameters-only Observe(log theta) (Gram build + blocked
-fp64 Cholesky + forward solve + LML) followed by Gradient() (triangular inverse,
+Cholesky + forward solve + LML) followed by Gradient() (triangular inverse,
 K^-1, fused gradient reduction), theta changing every step.  X, y are resident
-in HBM before the timed region starts.  Workload: BASELINE.json configs[2]
-(RBF + white noise, N=16384, D=8, fp64, one MI355X).
+in HBM before the timed region starts.
 
-N > 1 in this round: every GPU evaluates its own hyperparameter candidate on
-the full data (the optimiser's multi-start / line-search candidates) -- weak
-scaling, no data-path collective; DESIGN.md "Multi-GPU" explains what comes next.
+--config selects the workload from BASELINE.json's `configs` (gogp_amd/configs.py);
+default 3 = the configuration the headline metric is quoted on (RBF + white noise,
+N=16384, D=8, fp64, one MI355X).
+
+N > 1:
+  * configs 1-3 (one evaluation fits and is quoted on ONE GPU): every GPU evaluates its
+    own hyperparameter candidate on the full data -- weak scaling, no data-path
+    collective; `value` is the replica throughput; ONE evaluation sharded over all ranks
+    is timed as well and reported as `sharded_evaluation`;
+  * configs 4-5 (BASELINE quotes them as ONE evaluation over all GPUs): `value` is the
+    throughput of the 2-D block-cyclic sharded evaluation (strong scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   "roofline":     the dominant kernel (fp64 MFMA GEMM/SYRK tile kernel), HIP-event
-                  timed on the stream it is launched on during the timed region;
-  "cpu_baseline": the CPU oracle's numpy/scipy twin ("port") on a bounded sample.
+                  timed on the streams it is launched on during the timed region;
+  "cpu_baseline": the CPU oracle's numpy/scipy twin ("port") timed on the host cores, at
+                  the FULL size of the workload when N <= 16384 (so that the LML /
+                  gradient / mu / sigma errors are measured on the metric's own
+                  configuration), on a bounded sample otherwise.
 """
 import argparse
 import json
@@ -33,6 +43,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6  # AMD public spec, fp64 matrix = vector
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+ORACLE_FULL_N_LIMIT = 16384
 
 
 def host_cores():
@@ -48,42 +60,64 @@ def host_cores():
     return n
 
 
-def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
-    """Time the oracle's fast twin on the first `sample_n` rows of the same
-    workload; returns the cpu_baseline object and the LML relative error of the
-    GPU path on that same sample."""
+def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
+    """Time the oracle's fast twin on the first `sample_n` rows of the workload (the whole
+    workload when sample_n == N) and compare the GPU path with it on the same rows."""
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # before the C oracle (libgomp) is loaded
     from threadpoolctl import threadpool_limits
-    from gogp_amd import kernel, synth
     from oracle.oracle import FastOracle, Oracle  # checker / baseline only
     threadpool_limits(limits=cores)
-    X, y = synth.make_inputs(N, D, seed)
-    Xs, ys = X[:sample_n], y[:sample_n]
-    o = FastOracle(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, block=2048)
-    o.set_data(Xs, ys)
-    x = synth.log_theta_cycle(D, 0)
-    t0 = time.time()
-    lml = o.Observe(x)
-    g = o.Gradient()
-    dt = time.time() - t0
-    threads = cores
+    N, D = wl.N, wl.D
+    X, y = wl.inputs()
+    x = wl.log_theta(0)
+    Z = wl.test_points(1024 if N >= 1024 else 16)
+
+    def run(n):
+        o = FastOracle(D, wl.simil, wl.noise, block=2048)
+        o.set_data(X[:n], y[:n])
+        t0 = time.time()
+        lml = o.Observe(x)
+        g = o.Gradient()
+        dt = time.time() - t0
+        return o, lml, g, dt
+
+    # untimed warm-up: thread pools, first-touch page-in of OpenBLAS / libgomp
+    run(min(1024, sample_n))
+    o, lml, g, dt = run(sample_n)
+    full = sample_n == N
     scale = (sample_n / float(N)) ** 3
     out = {
         "value": (1.0 / dt) * scale,
         "unit": "evals/s",
-        "cores": int(threads),
+        "cores": int(cores),
         "kind": "port",
-        "sample": "1 Observe+Gradient at N=%d D=%d (first rows of the same inputs), %.1f s of "
-                  "scipy/OpenBLAS potrf+potri+potrs and C/OpenMP Gram + gradient pair loops; scaled by (%d/%d)^3 to N=%d"
-                  % (sample_n, D, dt, sample_n, N, N),
-        "measured_evals_per_s_at_sample": 1.0 / dt,
+        "sample": ("1 Observe+Gradient at N=%d D=%d (%s), %.1f s of scipy/OpenBLAS potrf+potri+potrs and "
+                   "C/OpenMP Gram + gradient pair loops%s"
+                   % (sample_n, D, "the FULL workload" if full else "first rows of the same inputs", dt,
+                      "" if full else "; scaled by (%d/%d)^3 to N=%d" % (sample_n, N, N))),
+        "measured_at_full_n": bool(full),
+        "seconds": dt,
     }
+    mu, sigma = o.Produce(Z)
+    lml_gpu, g_gpu, mu_gpu, sigma_gpu = gpu_fn(X[:sample_n], y[:sample_n], x, Z)
+    errs = {
+        "n": sample_n,
+        "lml_rel_err_vs_oracle": abs(lml_gpu - lml) / abs(lml),
+        "grad_rel_err_vs_oracle": float(np.abs(g_gpu - g).max() / max(1.0, np.abs(g).max())),
+        "mu_rel_err_vs_oracle": float(np.abs(mu_gpu - mu).max() / max(1e-300, np.abs(mu).max())),
+        "sigma_rel_err_vs_oracle": float(np.abs(sigma_gpu - sigma).max() / max(1e-300, np.abs(sigma).max())),
+    }
+    del o
+    if second_sample_n and second_sample_n < sample_n:
+        _, _, _, dt2 = run(second_sample_n)
+        out["second_sample"] = {"n": second_sample_n, "seconds": dt2,
+                                "evals_per_s_scaled_to_N": (1.0 / dt2) * (second_sample_n / float(N)) ** 3}
     # the reference's own algorithm (dense dK per parameter, r0 = aa^T dK, r1 = K^-1 dK:
     # gp/gp.go:476-485; 4P N^3 flop) as restated by the faithful C oracle, single thread,
     # at a size it finishes in about a second, extrapolated by its N^3 law (SURVEY 8d)
-    nf = min(512, sample_n)
-    of = Oracle(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise)
+    nf = min(512 if wl.P <= 4 else 256, sample_n)
+    of = Oracle(D, wl.simil, wl.noise)
     of.set_data(X[:nf], y[:nf])
     t0 = time.time()
     of.Observe(x)
@@ -94,29 +128,36 @@ def cpu_baseline(N, D, seed, sample_n, lml_gpu_fn):
         "extrapolated_evals_per_s": (1.0 / dtf) * (nf / float(N)) ** 3,
         "note": "dense-dK algorithm of gp/gp.go:418-499 in C (no AD tape, no Go runtime), "
                 "scaled by (n/N)^3"}
-    Z = synth.make_test_points(1024, D, seed + 1)
-    mu, sigma = o.Produce(Z)
-    lml_gpu, g_gpu, mu_gpu, sigma_gpu = lml_gpu_fn(Xs, ys, x, Z)
-    rel = abs(lml_gpu - lml) / abs(lml)
-    grel = float(np.abs(g_gpu - g).max() / max(1.0, np.abs(g).max()))
-    murel = float(np.abs(mu_gpu - mu).max() / max(1e-300, np.abs(mu).max()))
-    sgrel = float(np.abs(sigma_gpu - sigma).max() / max(1e-300, np.abs(sigma).max()))
-    return out, rel, grel, murel, sgrel
+    return out, errs
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of the same
+    command (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py from separate
+    rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 correction); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            d = json.load(f)
+        return d.get(str(config))
+    except Exception:
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nobs", type=int, default=16384)
-    ap.add_argument("--ndim", type=int, default=8)
-    ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5])
+    ap.add_argument("--nobs", type=int, default=None)
+    ap.add_argument("--ndim", type=int, default=None)
+    ap.add_argument("--cpu-sample-n", type=int, default=8192,
+                    help="CPU baseline sample when the full workload is too large for the oracle")
     ap.add_argument("--no-produce", action="store_true",
                     help="skip the secondary Produce measurement (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
-    ap.add_argument("--sharded-timeout", type=int, default=240)
+    ap.add_argument("--sharded-timeout", type=int, default=300)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,75 +172,134 @@ def main():
     backend = os.environ.get("GOGP_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    from gogp_amd import configs
     from gogp_amd import dist as gd
-    from gogp_amd import kernel, synth
     from gogp_amd import gp as G
     gd.init(backend, torch.device("cuda", local_rank))
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    N, D = args.nobs, args.ndim
-    seed = 20251114 + 2  # seed = 20251114 + config index
-    X, y = synth.make_inputs(N, D, seed)
-    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
-    g = G.GP(D, simil, noise, device=local_rank)
-    # inputs resident in HBM before anything is timed
-    dX = torch.from_numpy(X).to("cuda")
-    dy = torch.from_numpy(y).to("cuda")
-    torch.cuda.synchronize()
-    g.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
-
-    def step(k):
-        lml = g.Observe(synth.log_theta_cycle(D, k, rank))
-        grad = g.Gradient()
-        return lml, grad
-
-    for k in range(args.warmup):
-        step(k)
+    wl = configs.workload(args.config, args.nobs, args.ndim)
+    N, D = wl.N, wl.D
+    big = N > 20000
+    steps = args.steps if args.steps is not None else (3 if N > 40000 else 5 if big else 10 if N > 6000 else 50)
+    warmup = args.warmup if args.warmup is not None else (1 if big else 2)
+    sharded_value = wl.sharded and world > 1  # `value` = the sharded evaluation
+    X, y = wl.inputs()
+    simil, noise = wl.simil, wl.noise
 
     def sync():
         gd.barrier()
         torch.cuda.synchronize()
 
-    g.profile_enable(True)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        lml, grad = step(args.warmup + k)
-    sync()
-    dt = time.perf_counter() - t0
-    gemm_ms, gemm_launches, gemm_flops, gemm_busy_ms = g.profile_read()
-    g.profile_enable(False)
-    dt = gd.max_over_ranks(dt, device=red_dev)
+    # Watchdog for everything that involves a collective on a path that cannot be rehearsed on
+    # real multi-GPU RCCL before the driver runs it: if it hangs, rank 0 prints what it has
+    # and EVERY rank exits non-zero, so the driver records the hang as a failure.
+    out_holder = {"line": None}
+    wd = None
+    if world > 1:
+        import threading
+
+        def _bail():
+            if rank == 0:
+                line = out_holder["line"] or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
+                line["error"] = "collective timed out after %d s" % args.sharded_timeout
+                print(json.dumps(line), flush=True)
+            os._exit(3)
+
+        wd = threading.Timer(args.sharded_timeout, _bail)
+        wd.daemon = True
+        wd.start()
+
+    out = None
+    g = None
+    if not sharded_value:
+        g = G.GP(D, simil, noise, device=local_rank)
+        # inputs resident in HBM before anything is timed
+        dX = torch.from_numpy(X).to("cuda")
+        dy = torch.from_numpy(y).to("cuda")
+        torch.cuda.synchronize()
+        g.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
+
+        def step(k):
+            lml = g.Observe(wl.log_theta(k, rank))
+            grad = g.Gradient()
+            return lml, grad
+
+        for k in range(warmup):
+            step(k)
+        g.profile_enable(True)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            lml, grad = step(warmup + k)
+        sync()
+        dt = time.perf_counter() - t0
+        gemm_ms, gemm_launches, gemm_flops, gemm_busy_ms = g.profile_read()
+        gram_ms, gram_n = g.profile_read_aux(0)
+        grad_ms, grad_n = g.profile_read_aux(1)
+        g.profile_enable(False)
+        dt = gd.max_over_ranks(dt, device=red_dev)
+        value = world * steps / dt
+        par_text = ("1 evaluation per GPU" if world == 1 else
+                    "replicas: %d independent evaluations (one candidate theta per GPU)" % world)
+        scaling = "weak"
+    else:
+        from gogp_amd.sharded import ShardedGP
+        sg = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank)
+
+        def step(k):
+            lml = sg.Observe(wl.log_theta(k))  # the same theta on every rank: ONE evaluation
+            grad = sg.Gradient()
+            return lml, grad
+
+        for k in range(warmup):
+            step(k)
+        sg.profile_enable(True)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            lml, grad = step(warmup + k)
+        sync()
+        dt = time.perf_counter() - t0
+        gemm_ms, gemm_launches, gemm_flops, gemm_busy_ms = sg.profile_read()
+        gram_ms = gram_n = grad_ms = grad_n = 0
+        sg.profile_enable(False)
+        dt = gd.max_over_ranks(dt, device=red_dev)
+        value = steps / dt
+        par_text = "ONE evaluation sharded 2-D block-cyclically over a %s grid of GPUs (%s)" % (
+            sg.grid_text(), sg.transport_text())
+        scaling = "strong"
 
     if rank == 0:
         algo_flops_step = float(N) ** 3  # N^3/3 Cholesky + 2N^3/3 inverse
-        # The kernel's launches overlap (four streams): its busy time is the union of the
-        # event-timed launch intervals, not their sum.
-        achieved = (algo_flops_step * args.steps / (gemm_busy_ms * 1e-3) / 1e12
-                    if gemm_busy_ms > 0 else 0.0)
+        # The kernel's launches overlap (several streams): its busy time is the union of the
+        # event-timed launch intervals, not their sum.  On a sharded run the counters are rank
+        # 0's and the algorithmic work per rank is N^3 / world.
+        per_rank = algo_flops_step / (world if sharded_value else 1)
+        achieved = (per_rank * steps / (gemm_busy_ms * 1e-3) / 1e12 if gemm_busy_ms > 0 else 0.0)
         try:
             peak_cal = G.mfma_f64_peak(20000, local_rank)
         except Exception:
             peak_cal = None
         out = {
-            "metric": "GP.Observe+Gradient evals/sec (fp64) at N=%d D=%d" % (N, D),
-            "value": world * args.steps / dt,
+            "metric": "GP.Observe+Gradient evals/sec (%s) at N=%d D=%d" % (
+                "fp64" if wl.dtype == "f64" else "fp32", N, D),
+            "value": value,
             "unit": "evals/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": wl.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: RBF + white noise, N=%d D=%d fp64, Observe+Gradient "
-                            "(hyperparameters-only form), theta perturbed every step" % (N, D),
-                "N": N, "D": D, "kernel": "c*RBF(l) + sigma^2 I", "P": 3,
-                "parallelism": "1 evaluation per GPU" if world == 1 else
-                               "replicas: %d independent evaluations (one candidate theta per GPU)" % world,
+                "workload": wl.name + ", Observe+Gradient (hyperparameters-only form), theta perturbed "
+                                      "every step",
+                "baseline_config": wl.config, "N": N, "D": D, "kernel": wl.kernel_text, "P": wl.P,
+                "parallelism": par_text,
             },
             "lml": lml,
             "roofline": {
@@ -209,103 +309,138 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
+                "frac_wall": (per_rank / (dt / steps) / 1e12) / FP64_PEAK_TFLOPS,
                 "traffic": None,
                 "algorithmic_flops_per_step": algo_flops_step,
-                "launches_per_step": gemm_launches / max(1, args.steps),
+                "launches_per_step": gemm_launches / max(1, steps),
                 "avg_launch_ms": gemm_ms / max(1, gemm_launches),
-                "kernel_busy_ms_per_step": gemm_busy_ms / max(1, args.steps),
-                "sum_of_launch_durations_ms_per_step": gemm_ms / max(1, args.steps),
+                "kernel_busy_ms_per_step": gemm_busy_ms / max(1, steps),
+                "sum_of_launch_durations_ms_per_step": gemm_ms / max(1, steps),
                 "launch_concurrency": gemm_ms / gemm_busy_ms if gemm_busy_ms > 0 else None,
-                "launched_flops_per_step": gemm_flops / max(1, args.steps),
+                "launched_flops_per_step": gemm_flops / max(1, steps),
                 "peak_calibrated_mfma_f64": peak_cal,
                 "note": "achieved = N^3 algorithmic flop per step / HIP-event-timed busy time of the "
-                        "kernel per step (union of its launch intervals: launches overlap on 4 streams; "
-                        "rocprofv3 --stats sums them, see sum_of_launch_durations_ms_per_step = "
-                        "avg_launch_ms x launches_per_step); peak = 78.6 TFLOP/s spec; peak_calibrated = "
-                        "sustained v_mfma_f64 issue-rate microbenchmark on this device",
+                        "kernel per step (union of its launch intervals: launches overlap on several "
+                        "streams; rocprofv3 --stats sums them, see sum_of_launch_durations_ms_per_step = "
+                        "avg_launch_ms x launches_per_step); frac_wall = the same flop / wall time per "
+                        "step (a lower bound that needs no event arithmetic); peak = 78.6 TFLOP/s spec; "
+                        "peak_calibrated = sustained v_mfma_f64 issue-rate microbenchmark on this device",
             },
         }
-        if world == 1 and not args.no_produce:
+        tr = pmc_traffic(wl.config)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_note"] = tr.get("note")
+        if gram_n and grad_n:
+            w = 512  # the first super-panel's block columns are built on the panel stream
+            gram_bytes = 8.0 * max(0, N - w) ** 2 / 2.0
+            grad_bytes = 8.0 * float(N) * N / 2.0
+            out["hbm_bound_kernels"] = {
+                "gram_build": {"algorithmic_bytes": gram_bytes, "ms": gram_ms / gram_n,
+                               "GBps": gram_bytes / (gram_ms / gram_n * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": gram_bytes / (gram_ms / gram_n * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "grad_reduce": {"algorithmic_bytes": grad_bytes, "ms": grad_ms / grad_n,
+                                "GBps": grad_bytes / (grad_ms / grad_n * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": grad_bytes / (grad_ms / grad_n * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "note": "8 B per lower-triangle element written (Gram; the part built on the main "
+                        "stream) / read (K^-1 in the fused gradient reduction); HIP events on the "
+                        "kernel's stream"}
+        if world == 1 and not args.no_produce and g is not None:
             # secondary metric: Produce throughput at the same N, M = 1024 fresh
             # test points per call, host Z in / host mu, sigma out -- outside the timed region
-            Zp = synth.make_test_points(1024, D, seed + 1)
+            M = 1024 if N >= 1024 else 16
+            Zp = wl.test_points(M)
             g.Produce(Zp)
             torch.cuda.synchronize()
+            g.profile_enable(True)
             tp = time.perf_counter()
             for _ in range(3):
                 mu_p, sigma_p = g.Produce(Zp)
             tp = (time.perf_counter() - tp) / 3
-            out["produce"] = {"m": 1024, "ms_per_call": tp * 1e3, "test_points_per_s": 1024 / tp,
+            cross_ms, cross_n = g.profile_read_aux(2)
+            g.profile_enable(False)
+            out["produce"] = {"m": M, "ms_per_call": tp * 1e3, "test_points_per_s": M / tp,
                               "note": "Kstar build + mu = Kstar^T alpha + blocked solve V^T = Kstar^T L^-T "
                                       "(N^2 M flop on the tile kernel) + column norms, factor resident"}
-        out_holder = out
-    else:
-        out_holder = None
+            if cross_n:
+                cb = 8.0 * N * M
+                out["produce"]["cross_kernel"] = {"algorithmic_bytes": cb, "ms": cross_ms / cross_n,
+                                                  "GBps": cb / (cross_ms / cross_n * 1e-3) / 1e9}
+        out_holder["line"] = out
 
-    # ---- N > 1: also time ONE evaluation sharded over all ranks (latency mode) ----------
-    # Not part of `value` (replica throughput); reported so that the driver's multi-GPU
-    # run measures the block-cyclic path on real xGMI.  Any failure is reported, not fatal.
+    # ---- N > 1, replica configs: also time ONE evaluation sharded over all ranks ------------
     sharded = None
-    if world > 1 and not args.no_sharded:
-        # Watchdog: the sharded path cannot be rehearsed on real multi-GPU RCCL before the
-        # driver runs it.  If a collective hangs, every rank exits cleanly after the limit
-        # and rank 0 still prints its ONE line (replica result + the timeout note).
-        import threading
-
-        def _bail():
-            if rank == 0 and out_holder is not None:
-                out_holder["sharded_evaluation"] = {"error": "timeout after %d s" % args.sharded_timeout}
-                print(json.dumps(out_holder), flush=True)
-            os._exit(0)
-
-        wd = threading.Timer(args.sharded_timeout, _bail)
-        wd.daemon = True
-        wd.start()
+    if world > 1 and not sharded_value and not args.no_sharded:
         try:
             from gogp_amd.sharded import ShardedGP
             sg = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank)
-            sg.Observe(synth.log_theta_cycle(D, 0))
+            sg.Observe(wl.log_theta(0))
             sg.Gradient()
             sync()
             t0 = time.perf_counter()
             nrep = 3
             for k in range(nrep):
-                lml_s = sg.Observe(synth.log_theta_cycle(D, 1 + k))
+                lml_s = sg.Observe(wl.log_theta(1 + k))
                 grad_s = sg.Gradient()
             sync()
             dts = gd.max_over_ranks((time.perf_counter() - t0) / nrep, device=red_dev)
             # same theta on a single GPU for the agreement check
-            lml_1 = g.Observe(synth.log_theta_cycle(D, nrep))
+            lml_1 = g.Observe(wl.log_theta(nrep))
             grad_1 = g.Gradient()
             sharded = {"ms_per_eval": dts * 1e3, "n_gpus": world, "evals_per_s": 1.0 / dts,
-                       "layout": "1-D block-cyclic 512-wide super-panels, panel broadcast via "
-                                 "torch.distributed (%s)" % backend,
+                       "layout": "2-D block-cyclic, grid %s, %s" % (sg.grid_text(), sg.transport_text()),
+                       "bytes_per_rank": sg.local_bytes(),
                        "lml_rel_diff_vs_single_gpu": abs(lml_s - lml_1) / abs(lml_1),
                        "grad_rel_diff_vs_single_gpu":
                            float(np.abs(grad_s - grad_1).max() / max(1.0, np.abs(grad_1).max()))}
             sg.close()
         except Exception as e:  # noqa: BLE001
             sharded = {"error": repr(e)[:300]}
+    elif sharded_value:
+        # agreement of the sharded evaluation with ONE GPU running the same evaluation alone
+        try:
+            kk = warmup + steps - 1
+            if rank == 0:
+                g1 = G.GP(D, simil, noise, X=X, Y=y, device=local_rank)
+                lml_1 = g1.Observe(wl.log_theta(kk))
+                grad_1 = g1.Gradient()
+                g1.close()
+                sharded = {"bytes_per_rank": sg.local_bytes(),
+                           "lml_rel_diff_vs_single_gpu": abs(lml - lml_1) / abs(lml_1),
+                           "grad_rel_diff_vs_single_gpu":
+                               float(np.abs(grad - grad_1).max() / max(1.0, np.abs(grad_1).max()))}
+            sync()
+            sg.close()
+        except Exception as e:  # noqa: BLE001
+            sharded = {"error": repr(e)[:300]}
+    if wd is not None:
         wd.cancel()
 
     if rank == 0:
-        out = out_holder
         if sharded is not None:
             out["sharded_evaluation"] = sharded
         if world == 1 and not args.no_cpu_baseline:
-            def lml_gpu_fn(Xs, ys, x, Z):
-                g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank)
+            def gpu_fn(Xs, ys, x, Z):
+                if len(ys) == N and g is not None:
+                    g2 = g  # the full workload is already resident
+                else:
+                    g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank)
                 v = g2.Observe(x)
                 gr = g2.Gradient()
                 mu, sigma = g2.Produce(Z)
-                g2.close()
+                if g2 is not g:
+                    g2.close()
                 return v, gr, mu, sigma
-            cb, rel, grel, murel, sgrel = cpu_baseline(N, D, seed, min(args.cpu_sample_n, N), lml_gpu_fn)
+            full = N <= ORACLE_FULL_N_LIMIT
+            sample = N if full else min(args.cpu_sample_n, N)
+            cb, errs = cpu_baseline(wl, sample, gpu_fn,
+                                    second_sample_n=(8192 if full and N > 8192 else 0))
             out["cpu_baseline"] = cb
-            out["lml_rel_err_vs_oracle"] = rel
-            out["grad_rel_err_vs_oracle"] = grel
-            out["mu_rel_err_vs_oracle"] = murel
-            out["sigma_rel_err_vs_oracle"] = sgrel
+            out["parity_vs_oracle"] = errs
+            out["lml_rel_err_vs_oracle"] = errs["lml_rel_err_vs_oracle"]
+            out["grad_rel_err_vs_oracle"] = errs["grad_rel_err_vs_oracle"]
+            out["mu_rel_err_vs_oracle"] = errs["mu_rel_err_vs_oracle"]
+            out["sigma_rel_err_vs_oracle"] = errs["sigma_rel_err_vs_oracle"]
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

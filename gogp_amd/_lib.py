@@ -45,6 +45,8 @@ SYMBOLS = [
     ("gogp_n", _i64, [_h]),
     ("gogp_get_alpha", ctypes.c_int, [_h, _dp]),
     ("gogp_get_factor", ctypes.c_int, [_h, _dp]),
+    ("gogp_get_factor_rows", ctypes.c_int, [_h, ctypes.POINTER(_i64), _i64, _dp]),
+    ("gogp_get_factor_diag", ctypes.c_int, [_h, _dp]),
     ("gogp_set_factor", ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
     ("gogp_dist_staging_bytes", _i64, [_i64]),
     ("gogp_dist_setup", ctypes.c_int,
@@ -52,6 +54,7 @@ SYMBOLS = [
       ctypes.c_void_p, _i64]),
     ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
+    ("gogp_profile_read_aux", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.POINTER(_i64)]),
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
     ("gogp_version", ctypes.c_char_p, []),
 ]

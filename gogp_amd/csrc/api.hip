@@ -28,86 +28,11 @@
 #include <new>
 #include <utility>
 
-#include "common.h"
-
+#include "handle.h"
 
 using namespace gogp;
 
 static thread_local std::string g_create_error;
-
-struct gogp_handle {
-  gogp_desc desc;
-  int device = 0;
-  int ns = 0, nn = 0, P = 0, D = 0;
-  int ard_dims = 0;
-  int64_t n = 0, npad = 0;
-  int nblk = 0;  // 128-blocks
-  // device buffers
-  double *dX = nullptr, *dy = nullptr;
-  double *bufA = nullptr, *bufL = nullptr, *bufY = nullptr, *Dinv = nullptr;
-  double *z = nullptr, *w = nullptr, *alpha = nullptr;
-  double *scalars = nullptr;  // 8 doubles
-  long long *info = nullptr;
-  double *gpart = nullptr, *gout = nullptr;
-  DevParams *devP = nullptr;
-  DevParams *hostP = nullptr;  // pinned
-  double *hscal = nullptr;     // pinned staging, NACC + 16 doubles
-  int64_t cap_npad = 0;        // allocation size of the N-dependent buffers
-  int64_t cap_y = 0;           // npad bufY was allocated for (it is allocated lazily)
-  // produce workspace
-  double *dZ = nullptr, *KsT = nullptr, *Vt = nullptr, *pvec = nullptr;
-  int64_t cap_m = 0, cap_mp_npad = 0;
-  hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
-  hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
-                             // skinny updates, substitution steps -- overlaps the big updates
-  // sharded evaluation (gogp_dist_setup); dist_n <= 1: single GPU
-  int dist_rank = 0, dist_n = 1;
-  gogp_bcast_fn dist_bcast = nullptr;
-  gogp_allreduce_fn dist_allreduce = nullptr;
-  void *dist_user = nullptr;
-  double *dist_staging = nullptr;
-  int64_t dist_staging_bytes = 0;
-  hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)
-  hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
-  hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
-  void *stream_set = nullptr;  // the pooled StreamSet the five streams belong to
-  std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
-  int lookahead = 1;
-  int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
-  int eager = 1;               // Observe also runs the triangular inverse (gradient
-                               // preparation), interleaved with the Cholesky sweep
-  bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
-  bool trtri_pending = false;  // ... and still running on st/s2 (wait for EV_TRTRI)
-  bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
-  // state
-  std::vector<double> theta_s, theta_n;
-  bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
-  bool observed = false, with_obs = false;
-  double lml = 0.0;
-  std::vector<double> grad_cache;
-  bool grad_valid = false;
-  int64_t notpd = -1;
-  std::string err;
-  GemmProfile prof;
-};
-
-#define HIPCHK(h, call)                                                                \
-  do {                                                                                 \
-    hipError_t e_ = (call);                                                            \
-    if (e_ != hipSuccess) {                                                            \
-      char buf_[512];                                                                  \
-      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
-               __FILE__, __LINE__);                                                    \
-      (h)->err = buf_;                                                                 \
-      (void)hipGetLastError(); /* reset the sticky error: later calls must not see it */ \
-      return (e_ == hipErrorOutOfMemory) ? GOGP_ENOMEM : GOGP_EHIP;                     \
-    }                                                                                  \
-  } while (0)
-
-static int fail(gogp_handle *h, int code, const char *msg) {
-  if (h) h->err = msg;
-  return code;
-}
 
 // ---- descriptor helpers -------------------------------------------------------
 extern "C" int gogp_desc_ntheta_noise(const gogp_desc *d) {
@@ -256,6 +181,8 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (h->hostP) (void)hipHostFree(h->hostP);
   if (h->hscal) (void)hipHostFree(h->hscal);
   for (auto e : h->prof.pool) (void)hipEventDestroy(e);
+  for (auto &pool : h->aux_ev)
+    for (auto e : pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
   for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl})
     if (q) (void)hipStreamSynchronize(q);
@@ -402,26 +329,6 @@ static int upload_params(gogp_handle *h) {
   return GOGP_OK;
 }
 
-// ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_BASE = 8 };
-// per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
-//                              2: column panel p of Y final, 3: next column panel of R final}
-static hipEvent_t ev(gogp_handle *h, size_t i) {
-  while (h->evs.size() <= i) {
-    hipEvent_t e = nullptr;
-    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    h->evs.push_back(e);
-  }
-  return h->evs[i];
-}
-// "a then b": work enqueued on `to` after this call waits for everything
-// enqueued on `from` before it
-static void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
-  hipEvent_t e = ev(h, i);
-  (void)hipEventRecord(e, from);
-  (void)hipStreamWaitEvent(to, e, 0);
-}
-
 // bufY (Y = L^-T) is allocated on first use and tracked by its own capacity: the other
 // N-dependent buffers may have been sized by an Absorb that never needed it.
 static int ensure_y(gogp_handle *h) {
@@ -521,8 +428,11 @@ static int factorize(gogp_handle *h, bool eager) {
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), sp));
   // Gram matrix: the first super-panel's block columns on the panel stream -- the chain
   // starts ~30 us later instead of after the whole 0.5 ms build -- the rest on the main stream
-  launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld,
-                          (int64_t)h->superpanel * PANEL);
+  {
+    AuxTimer tm(h, GOGP_PROF_GRAM, s);  // the main-stream part: all but the first block columns
+    launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld,
+                            (int64_t)h->superpanel * PANEL);
+  }
   (void)hipEventRecord(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
                                             // is NOT implied: consumers of columns < 512 are on sp)
   if (eager) {
@@ -672,240 +582,6 @@ static int ensure_alpha(gogp_handle *h) {
   return GOGP_OK;
 }
 
-// ===========================================================================
-// Sharded evaluation: 1-D block-cyclic super-panels over dist_n ranks.
-// Everything runs on the main stream; broadcasts are host-synchronous (the
-// callback returns when the data have arrived).
-// ===========================================================================
-static int dist_owner(const gogp_handle *h, int P0) { return (P0 / h->superpanel) % h->dist_n; }
-
-extern "C" int64_t gogp_dist_staging_bytes(int64_t n) {
-  const int64_t npad = n <= 0 ? PANEL : ((n + PANEL - 1) / PANEL) * PANEL;
-  // a packed panel: up to npad rows x (4 * 256) columns + the diagonal inverses
-  return (npad * 4 * PANEL + 4 * (int64_t)PANEL * PANEL) * (int64_t)sizeof(double);
-}
-
-// Host-synchronous broadcast of the staging buffer.  Only the PANEL stream is
-// drained first (it carries the owner's chain + packing, and the previous unpack
-// that last read the staging buffer); the main stream keeps running its trailing
-// updates underneath the broadcast.
-static int dist_bcast(gogp_handle *h, int64_t bytes, int root) {
-  if (bytes > h->dist_staging_bytes) return fail(h, GOGP_EARG, "dist: staging buffer too small");
-  HIPCHK(h, hipStreamSynchronize(h->sp));
-  if (h->dist_bcast(h->dist_user, h->dist_staging, bytes, root) != 0)
-    return fail(h, GOGP_EHIP, "dist: broadcast callback failed");
-  return GOGP_OK;
-}
-
-// Streams: sp = owner's chain (diagonal blocks, panel solves), packing, unpacking,
-// replicated substitution steps; s = trailing updates of the owned block columns.
-// Per super-panel P:  [sp, owner] wait "my column is up to date" -> chain -> pack;
-// [host] drain sp, broadcast; [sp, others] unpack; [s] wait "panel P complete" ->
-// next owner's block columns first -> event -> the rest of my columns.  The chain and
-// the broadcast of P+1 therefore overlap the rest-update of P on every rank.
-static int factorize_dist(gogp_handle *h) {
-  const int64_t npad = h->npad, ld = npad;
-  hipStream_t s = h->s, sp = h->sp;
-  for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
-  h->trtri_pending = false;
-  h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
-  h->alpha_pending = false;
-  h->trtri_done = false;
-  h->notpd = -1;
-  int rc = upload_params(h);
-  if (rc != GOGP_OK) return rc;
-  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
-  // every rank builds the whole lower triangle (0.5 ms at N = 16384); it only ever
-  // reads the block columns it owns
-  launch_gram_lower(s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld);
-  order(h, EV_GRAM, s, sp);
-  double *A = h->bufA, *L = h->bufL;
-  GemmProfile *pf = &h->prof;
-  const int npanel = (int)(npad / PANEL);
-  const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
-  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
-  for (int P0 = 0; P0 < npanel; P0 += SW) {
-    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
-    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
-    const int owner = dist_owner(h, P0);
-    double *Dp0 = h->Dinv + (size_t)P0 * PANEL * PANEL;
-    const size_t dbytes = (size_t)nsub * PANEL * PANEL * sizeof(double);
-    const int64_t prow = npad - C0;  // packed panel rows C0 .. npad
-    const size_t pbytes = (size_t)prow * Kw * sizeof(double);
-    if (owner == me) {
-      // my block columns [C0, CE) are up to date: their last update ran on this (panel)
-      // stream, in order, at the end of the previous super-step
-      for (int q = 0; q < nsub; ++q) {
-        const int p = P0 + q;
-        const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
-        double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-        launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
-        const int mt2 = (int)((npad - c2) / TILE);
-        if (mt2 > 0)
-          launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
-                          L + c2 * ld + c0, ld, pf);
-        for (int64_t cr = c2; cr < CE; cr += PANEL)
-          launch_dgemm_nt(sp, GEMM_RECT, (int)((npad - cr) / TILE), 2, PANEL, -1.0,
-                          L + cr * ld + c0, ld, L + cr * ld + c0, ld, 1.0, A + cr * ld + cr, ld, pf);
-      }
-      // pack [diagonal inverses | L[C0:npad, C0:CE]] into the staging buffer
-      HIPCHK(h, hipMemcpyAsync(h->dist_staging, Dp0, dbytes, hipMemcpyDeviceToDevice, sp));
-      HIPCHK(h, hipMemcpy2DAsync((char *)h->dist_staging + dbytes, Kw * sizeof(double),
-                                 L + C0 * ld + C0, ld * sizeof(double), Kw * sizeof(double), prow,
-                                 hipMemcpyDeviceToDevice, sp));
-    }
-    rc = dist_bcast(h, (int64_t)(dbytes + pbytes), owner);
-    if (rc != GOGP_OK) return rc;
-    if (owner != me) {
-      HIPCHK(h, hipMemcpyAsync(Dp0, h->dist_staging, dbytes, hipMemcpyDeviceToDevice, sp));
-      HIPCHK(h, hipMemcpy2DAsync(L + C0 * ld + C0, ld * sizeof(double),
-                                 (char *)h->dist_staging + dbytes, Kw * sizeof(double),
-                                 Kw * sizeof(double), prow, hipMemcpyDeviceToDevice, sp));
-    }
-    order(h, EV_BASE + 4 * P0, sp, s);  // panel P complete on this rank
-    for (int q = 0; q < nsub; ++q)       // replicated: every rank keeps the full z
-      launch_trsv_fwd_step(sp, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
-    // trailing update of the block columns this rank owns (main stream)
-    const int mtE = (int)((npad - CE) / TILE);
-    if (mtE > 0) {
-      const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
-      if (dist_owner(h, P0 + SW) == me) {
-        // the next super-panel is mine: its block columns get this panel's update on the
-        // PANEL stream (the chain never crosses streams); they were last touched by my bulk
-        // update of the previous super-step
-        if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 1), 0);
-        launch_dgemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
-                        1.0, A + CE * ld + CE, ld, pf);
-      }
-      if (mtE > ntn) {
-        const int64_t C3 = CE + (int64_t)ntn * TILE;
-        const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
-        launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
-                        L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf, &own);
-      }
-      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // my bulk update of super-step P0 done
-    }
-  }
-  order(h, EV_FWD, sp, s);
-  launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
-  // alpha by backward substitution (replicated; every rank has the whole factor)
-  HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int b = npanel - 1; b >= 0; --b)
-    launch_trsv_bwd_step(s, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
-  HIPCHK(h, hipStreamSynchronize(s));
-  HIPCHK(h, hipStreamSynchronize(sp));
-  HIPCHK(h, hipGetLastError());
-  // the failing pivot is only seen by the rank that factored that block: agree on it
-  long long info = 0;
-  memcpy(&info, h->hscal + 8, sizeof info);
-  double flag = (double)info;
-  if (h->dist_allreduce(h->dist_user, &flag, 1) != 0) return fail(h, GOGP_EHIP, "dist: allreduce failed");
-  if (flag != 0.0) {
-    h->notpd = (info != 0) ? (int64_t)info - 1 : (int64_t)flag - 1;
-    h->err = "Factorize: matrix is not positive definite";
-    return GOGP_ENOTPD;
-  }
-  h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * h->hscal[0] - 0.5 * h->hscal[1];
-  h->factored = true;
-  h->have_alpha = true;
-  return GOGP_OK;
-}
-
-// Sharded triangular inverse + the owned tile rows of K^-1 = Y Y^T; same two-stream
-// scheme as factorize_dist (sp: owner's column panel of Y, pack / unpack; s: updates).
-static int compute_kinv_dist(gogp_handle *h) {
-  if (h->have_kinv) return GOGP_OK;
-  const int64_t npad = h->npad, ld = npad;
-  hipStream_t s = h->s, sp = h->sp;
-  GemmProfile *pf = &h->prof;
-  {
-    const int rcy = ensure_y(h);
-    if (rcy != GOGP_OK) return rcy;
-  }
-  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
-  const int npanel = (int)(npad / PANEL);
-  const int SW = h->superpanel, G = h->dist_n, me = h->dist_rank;
-  launch_zero_upper_blocks(s, R, ld, npad);
-  order(h, EV_INIT, s, sp);
-  for (int P0 = 0; P0 < npanel; P0 += SW) {
-    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
-    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, Kw = CE - C0;
-    const int owner = dist_owner(h, P0);
-    const size_t ybytes = (size_t)CE * Kw * sizeof(double);  // Y[0:CE, C0:CE]
-    if (owner == me) {
-      // R[0:C0, C0:CE] is final once my "next columns" update of the previous step is done
-      if (P0 > 0) (void)hipStreamWaitEvent(sp, ev(h, EV_BASE + 4 * (P0 - SW) + 3), 0);
-      for (int q = 0; q < nsub; ++q) {
-        const int p = P0 + q;
-        const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
-        const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-        launch_ydiag(sp, Dp, Y + c0 * ld + c0, ld);
-        if (c2 < CE) launch_zero_block(sp, Y + c2 * ld + c0, ld, CE - c2, PANEL);
-        if (c0 > 0)
-          launch_dgemm_nt(sp, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
-                          Y + c0, ld, pf);
-        if (c2 < CE)
-          launch_dgemm_nt(sp, GEMM_RECT, (int)(c2 / TILE), (int)((CE - c2) / TILE), PANEL, -1.0,
-                          Y + c0, ld, L + c2 * ld + c0, ld, 1.0, R + c2, ld, pf);
-      }
-      HIPCHK(h, hipMemcpy2DAsync(h->dist_staging, Kw * sizeof(double), Y + C0, ld * sizeof(double),
-                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, sp));
-    }
-    int rc = dist_bcast(h, (int64_t)ybytes, owner);
-    if (rc != GOGP_OK) return rc;
-    if (owner != me)
-      HIPCHK(h, hipMemcpy2DAsync(Y + C0, ld * sizeof(double), h->dist_staging, Kw * sizeof(double),
-                                 Kw * sizeof(double), CE, hipMemcpyDeviceToDevice, sp));
-    order(h, EV_BASE + 4 * P0 + 2, sp, s);  // column panel P of Y complete on this rank
-    const int nt = (int)((npad - CE) / TILE);
-    if (nt > 0) {
-      const int mr = (int)(CE / TILE);
-      const int ntn = nt < 2 * SW ? nt : 2 * SW;
-      if (dist_owner(h, P0 + SW) == me)
-        launch_dgemm_nt(s, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
-                        R + CE, ld, pf);
-      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s);
-      if (nt > ntn) {
-        const int64_t C3 = CE + (int64_t)ntn * TILE;
-        const GemmOwn own = {G, me, 2 * SW, (int)(C3 / TILE)};
-        launch_dgemm_nt(s, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
-                        R + C3, ld, pf, &own);
-      }
-    }
-  }
-  // K^-1 = Y Y^T: this rank's tile rows only (ti % G == me)
-  const GemmOwn rows = {G, me, 1, 0};
-  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, Y, ld, Y, ld, 0.0, h->bufA, ld, pf,
-                  &rows);
-  h->trtri_done = true;
-  h->have_kinv = true;
-  return GOGP_OK;
-}
-
-extern "C" int gogp_dist_setup(gogp_handle *h, int rank, int nranks, gogp_bcast_fn bcast,
-                               gogp_allreduce_fn allreduce, void *user, void *staging,
-                               int64_t staging_bytes) {
-  if (!h) return GOGP_EARG;
-  if (nranks <= 1) {
-    h->dist_n = 1;
-    h->dist_rank = 0;
-    return GOGP_OK;
-  }
-  if (rank < 0 || rank >= nranks || !bcast || !allreduce || !staging)
-    return fail(h, GOGP_EARG, "dist_setup: bad arguments");
-  h->dist_rank = rank;
-  h->dist_n = nranks;
-  h->dist_bcast = bcast;
-  h->dist_allreduce = allreduce;
-  h->dist_user = user;
-  h->dist_staging = (double *)staging;
-  h->dist_staging_bytes = staging_bytes;
-  h->factored = h->observed = h->grad_valid = h->have_kinv = false;
-  return GOGP_OK;
-}
-
 static int set_theta_natural(gogp_handle *h, const double *ts, const double *tn) {
   for (int i = 0; i < h->ns; ++i) {
     if (!(ts[i] > 0.0) || !std::isfinite(ts[i]))
@@ -934,7 +610,7 @@ extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
     h->factored = false;
     return GOGP_OK;
   }
-  rc = (h->dist_n > 1) ? factorize_dist(h) : factorize(h, false);
+  rc = h->dist ? dist_factorize(h, false) : factorize(h, false);
   if (rc != GOGP_OK) return rc;
   rc = ensure_alpha(h);  // gp/gp.go:232-236
   if (rc != GOGP_OK) return rc;
@@ -956,8 +632,8 @@ static int observe_theta(gogp_handle *h, const double *x, double *lml) {
     if (lml) *lml = 0.0;
     return GOGP_OK;
   }
-  rc = (h->dist_n > 1) ? factorize_dist(h)
-                       : factorize(h, h->eager != 0);  // gp/gp.go:402 (with gradient preparation)
+  rc = h->dist ? dist_factorize(h, true)
+               : factorize(h, h->eager != 0);  // gp/gp.go:402 (with gradient preparation)
   if (rc != GOGP_OK) return rc;
   h->observed = true;
   if (lml) *lml = h->lml;  // gp/gp.go:412
@@ -1037,21 +713,28 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
   for (int64_t i = 0; i < len; ++i) grad[i] = 0.0;
   if (h->n == 0) return GOGP_OK;  // gp/gp.go:427-430
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->dist_n > 1 && h->with_obs)
+  if (h->dist && h->with_obs)
     return fail(h, GOGP_EARG, "sharded evaluation: the full Observe form is not supported");
-  if (!h->grad_valid) {
-    int rc = (h->dist_n > 1) ? compute_kinv_dist(h) : compute_kinv(h);
+  if (!h->grad_valid && h->dist) {
+    // sharded: every rank reduces its own tiles of K^-1, one all-reduce of the slot sums
+    int rc = dist_gradient_sums(h, h->hscal + 16);
+    if (rc != GOGP_OK) return rc;
+  } else if (!h->grad_valid) {
+    int rc = compute_kinv(h);
     if (rc != GOGP_OK) return rc;
     rc = ensure_alpha(h);
     if (rc != GOGP_OK) return rc;
     hipStream_t s = h->s;
-    launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
-                       h->npad, h->gpart, h->gout, h->dist_n, h->dist_rank);
+    {
+      AuxTimer tm(h, GOGP_PROF_GRAD, s);
+      launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
+                         h->npad, h->gpart, h->gout);
+    }
     HIPCHK(h, hipMemcpyAsync(h->hscal + 16, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
-    if (h->dist_n > 1 && h->dist_allreduce(h->dist_user, h->hscal + 16, NACC) != 0)
-      return fail(h, GOGP_EHIP, "dist: allreduce failed");
+  }
+  if (!h->grad_valid) {
     const double *a = h->hscal + 16;
     h->grad_cache.assign(h->P, 0.0);
     const gogp_desc &d = h->desc;
@@ -1135,7 +818,10 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   if (rc != GOGP_OK) return rc;
   const int64_t npad = h->npad, ld = npad;
   double *R = h->KsT, *V = h->Vt, *L = h->bufL;
-  launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, R, ld);  // gp/gp.go:322-332
+  {
+    AuxTimer tm(h, GOGP_PROF_CROSS, s);
+    launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, R, ld);  // gp/gp.go:322-332
+  }
   // mean = Kstar^T alpha (gp/gp.go:335)
   launch_rownorm_dot(s, R, ld, h->alpha, npad, m, dmu, nullptr);
   // V^T = Kstar^T L^-T by blocked substitution on the GEMM kernel
@@ -1188,6 +874,39 @@ extern "C" int gogp_get_factor(gogp_handle *h, double *Lout) {
   if (e == hipSuccess) e = hipStreamSynchronize(h->s);
   (void)hipFree(tmp);
   HIPCHK(h, e);
+  return GOGP_OK;
+}
+
+extern "C" int gogp_get_factor_rows(gogp_handle *h, const int64_t *rows, int64_t nrows,
+                                    double *out) {
+  if (!h || nrows < 0 || (nrows > 0 && (!rows || !out))) return GOGP_EARG;
+  if (nrows == 0 || h->n == 0) return GOGP_OK;
+  if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
+  if (h->dist) return fail(h, GOGP_ESTATE, "L rows: not available on a sharded handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int64_t n = h->n;
+  for (int64_t r = 0; r < nrows; ++r)
+    if (rows[r] < 0 || rows[r] >= n) return fail(h, GOGP_EARG, "get_factor_rows: row out of range");
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t i = rows[r];
+    double *o = out + r * n;
+    HIPCHK(h, hipMemcpyAsync(o, h->bufL + (size_t)i * h->npad, (size_t)(i + 1) * sizeof(double),
+                             hipMemcpyDeviceToHost, h->s));
+    for (int64_t j = i + 1; j < n; ++j) o[j] = 0.0;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->s));
+  return GOGP_OK;
+}
+
+extern "C" int gogp_get_factor_diag(gogp_handle *h, double *diag) {
+  if (!h || (h->n > 0 && !diag)) return GOGP_EARG;
+  if (h->n == 0) return GOGP_OK;
+  if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
+  if (h->dist) return fail(h, GOGP_ESTATE, "L diagonal: not available on a sharded handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(diag, sizeof(double), h->bufL, (size_t)(h->npad + 1) * sizeof(double),
+                             sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->s));
+  HIPCHK(h, hipStreamSynchronize(h->s));
   return GOGP_OK;
 }
 
@@ -1244,6 +963,25 @@ extern "C" int gogp_profile_enable(gogp_handle *h, int on) {
   h->prof.used = 0;
   h->prof.flops = 0;
   h->prof.launches = 0;
+  for (auto &u : h->aux_used) u = 0;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches) {
+  if (!h || cls < 0 || cls >= GOGP_PROF_NCLASS) return GOGP_EARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+  double sum = 0.0;
+  int64_t cnt = 0;
+  for (size_t i = 0; i + 1 < h->aux_used[cls]; i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, h->aux_ev[cls][i], h->aux_ev[cls][i + 1]) != hipSuccess) continue;
+    sum += t;
+    ++cnt;
+  }
+  if (ms) *ms = sum;
+  if (launches) *launches = cnt;
+  h->aux_used[cls] = 0;
   return GOGP_OK;
 }
 

@@ -1,0 +1,130 @@
+// handle.h -- the handle behind the C ABI, shared by api.hip (single-GPU orchestration)
+// and dist2d.hip (2-D block-cyclic sharded evaluation).  Private to libgogp_hip.so.
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace gogp {
+struct Dist2D;  // dist2d.hip
+}
+
+struct gogp_handle {
+  gogp_desc desc;
+  int device = 0;
+  int ns = 0, nn = 0, P = 0, D = 0;
+  int ard_dims = 0;
+  int64_t n = 0, npad = 0;
+  int nblk = 0;  // 128-blocks
+  // device buffers
+  double *dX = nullptr, *dy = nullptr;
+  double *bufA = nullptr, *bufL = nullptr, *bufY = nullptr, *Dinv = nullptr;
+  double *z = nullptr, *w = nullptr, *alpha = nullptr;
+  double *scalars = nullptr;  // 8 doubles
+  long long *info = nullptr;
+  double *gpart = nullptr, *gout = nullptr;
+  DevParams *devP = nullptr;
+  DevParams *hostP = nullptr;  // pinned
+  double *hscal = nullptr;     // pinned staging, NACC + 16 doubles
+  int64_t cap_npad = 0;        // allocation size of the N-dependent buffers
+  int64_t cap_y = 0;           // npad bufY was allocated for (it is allocated lazily)
+  // produce workspace
+  double *dZ = nullptr, *KsT = nullptr, *Vt = nullptr, *pvec = nullptr;
+  int64_t cap_m = 0, cap_mp_npad = 0;
+  hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
+  hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
+                             // skinny updates, substitution steps -- overlaps the big updates
+  // sharded evaluation (gogp_dist_init_*): 2-D block-cyclic state, nullptr on a single GPU
+  gogp::Dist2D *dist = nullptr;
+  hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)
+  hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
+  hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
+  void *stream_set = nullptr;  // the pooled StreamSet the five streams belong to
+  std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
+  int lookahead = 1;
+  int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
+  int eager = 1;               // Observe also runs the triangular inverse (gradient
+                               // preparation), interleaved with the Cholesky sweep
+  bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
+  bool trtri_pending = false;  // ... and still running on st/s2 (wait for EV_TRTRI)
+  bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
+  // state
+  std::vector<double> theta_s, theta_n;
+  bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
+  bool observed = false, with_obs = false;
+  double lml = 0.0;
+  std::vector<double> grad_cache;
+  bool grad_valid = false;
+  int64_t notpd = -1;
+  std::string err;
+  GemmProfile prof;
+  // HIP-event timing of the O(N^2) kernels (gogp_profile_read_aux): class -> event pairs
+  std::vector<hipEvent_t> aux_ev[GOGP_PROF_NCLASS];
+  size_t aux_used[GOGP_PROF_NCLASS] = {0, 0, 0, 0};
+};
+
+// Bracket the launches of one O(N^2) kernel class with events on their stream (only while
+// profiling is enabled).
+struct AuxTimer {
+  gogp_handle *h;
+  int cls;
+  hipStream_t s;
+  hipEvent_t e1 = nullptr;
+  AuxTimer(gogp_handle *h_, int cls_, hipStream_t s_) : h(h_), cls(cls_), s(s_) {
+    if (!h->prof.on || cls < 0 || cls >= GOGP_PROF_NCLASS) return;
+    auto &pool = h->aux_ev[cls];
+    size_t &used = h->aux_used[cls];
+    while (pool.size() < used + 2) {
+      hipEvent_t e = nullptr;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    (void)hipEventRecord(pool[used], s);
+    e1 = pool[used + 1];
+    used += 2;
+  }
+  ~AuxTimer() {
+    if (e1) (void)hipEventRecord(e1, s);
+  }
+};
+
+#define HIPCHK(h, call)                                                                \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      char buf_[512];                                                                  \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+               __FILE__, __LINE__);                                                    \
+      (h)->err = buf_;                                                                 \
+      (void)hipGetLastError(); /* reset the sticky error: later calls must not see it */ \
+      return (e_ == hipErrorOutOfMemory) ? GOGP_ENOMEM : GOGP_EHIP;                     \
+    }                                                                                  \
+  } while (0)
+
+static inline int fail(gogp_handle *h, int code, const char *msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+// ---- cross-stream events -----------------------------------------------------------------
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_BASE = 8 };
+// per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
+//                              2: column panel p of Y final, 3: next column panel of R final}
+static inline hipEvent_t ev(gogp_handle *h, size_t i) {
+  while (h->evs.size() <= i) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    h->evs.push_back(e);
+  }
+  return h->evs[i];
+}
+// "a then b": work enqueued on `to` after this call waits for everything
+// enqueued on `from` before it
+static inline void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = ev(h, i);
+  (void)hipEventRecord(e, from);
+  (void)hipStreamWaitEvent(to, e, 0);
+}
+

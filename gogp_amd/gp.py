@@ -225,6 +225,24 @@ class GP:
             self._check(_lib.lib().gogp_get_factor(self._h, _dp(out)))
         return out
 
+    def L_rows(self, rows) -> np.ndarray:
+        """Selected rows of L (len(rows) x n), for checks at sizes where the whole factor
+        is not wanted on the host."""
+        n = int(_lib.lib().gogp_n(self._h))
+        idx = np.ascontiguousarray(np.asarray(rows, dtype=np.int64))
+        out = np.zeros((idx.size, n))
+        if n and idx.size:
+            self._check(_lib.lib().gogp_get_factor_rows(
+                self._h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), idx.size, _dp(out)))
+        return out
+
+    def L_diag(self) -> np.ndarray:
+        n = int(_lib.lib().gogp_n(self._h))
+        d = np.zeros(n)
+        if n:
+            self._check(_lib.lib().gogp_get_factor_diag(self._h, _dp(d)))
+        return d
+
     def restore(self, L, Alpha) -> None:
         """Produce on stored results (gp/gp.go:255-257): re-install ThetaSimil,
         ThetaNoise, X, L, Alpha without refactorising."""
@@ -247,6 +265,13 @@ class GP:
         self._check(_lib.lib().gogp_profile_read(self._h, ctypes.byref(ms), ctypes.byref(nl),
                                                  ctypes.byref(fl), ctypes.byref(bz)))
         return ms.value, nl.value, fl.value, bz.value
+
+    def profile_read_aux(self, cls: int):
+        """(sum of durations ms, timed launch groups) of one O(N^2) kernel class:
+        0 Gram build, 1 gradient reduction, 2 cross-covariance (Produce)."""
+        ms, nl = ctypes.c_double(0), ctypes.c_int64(0)
+        self._check(_lib.lib().gogp_profile_read_aux(self._h, int(cls), ctypes.byref(ms), ctypes.byref(nl)))
+        return ms.value, nl.value
 
 
 class Model:

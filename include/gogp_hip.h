@@ -176,6 +176,13 @@ int gogp_get_alpha(gogp_handle *h, double *alpha /* n */);
 /* Lower Cholesky factor, row-major n x n, upper triangle zero-filled.
  * (gonum stores U = L^T; the Go shim transposes when filling gp.GP.L.) */
 int gogp_get_factor(gogp_handle *h, double *L /* n*n */);
+/* Selected rows of the factor: out is nrows x n row-major, row r = L[rows[r], 0..n-1]
+ * (zeros right of the diagonal); and its diagonal (n doubles).  gp.GP.L at sizes where
+ * the whole n x n matrix is not wanted on the host (2*sum(log diag) is the LogDet of
+ * gp/gp.go:250). */
+int gogp_get_factor_rows(gogp_handle *h, const int64_t *rows, int64_t nrows,
+                         double *out /* nrows*n */);
+int gogp_get_factor_diag(gogp_handle *h, double *diag /* n */);
 /* Restore stored results so that gogp_produce works without re-absorbing
  * ("Produce on stored results", gp/gp.go:255-257). */
 int gogp_set_factor(gogp_handle *h, const double *theta_simil,
@@ -217,6 +224,14 @@ int gogp_profile_enable(gogp_handle *h, int on);
  * the accumulators. */
 int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
                       double *gemm_flops, double *gemm_busy_ms);
+
+/* The same for the bandwidth-bound O(N^2) kernels: sum of the event-measured durations
+ * (ms) and number of timed launch groups of one class since the last read. */
+#define GOGP_PROF_GRAM 0  /* Gram build (the main-stream part: all but the first 512 columns) */
+#define GOGP_PROF_GRAD 1  /* fused gradient reduction over K^-1 */
+#define GOGP_PROF_CROSS 2 /* cross-covariance build of Produce */
+#define GOGP_PROF_NCLASS 4
+int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches);
 
 /* Scheduling knobs (the results do not depend on them beyond rounding; the defaults are the
  * measured optimum).  Unknown name or out-of-range value: GOGP_EARG.

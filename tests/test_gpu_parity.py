@@ -346,6 +346,33 @@ def test_barebones_csv_config1(gpmod, golden_dir):
     np.testing.assert_allclose(g.Gradient(), o.Gradient(), rtol=1e-8, atol=1e-9)
 
 
+def _factor_check(g, y, krow_fn, lml, rng, nrows=6):
+    """Checks usable at sizes the oracle cannot reach: (a) sampled rows of L reproduce the Gram
+    matrix, sum_k L_ik L_jk = K_ij for every j <= i of the sampled rows i (K rows rebuilt on
+    the host from the kernel formula, noise on the diagonal), with the rows of L for the
+    sampled columns fetched as well; (b) the log-determinant 2 sum_i log L_ii recomputed on
+    the host from the downloaded diagonal, together with y^T alpha, reproduces the LML value
+    the library returned (gp/gp.go:244-253)."""
+    n = len(y)
+    rows = np.unique(np.concatenate([rng.integers(0, n, nrows), [0, n - 1]]))
+    Lr = g.L_rows(rows)  # len(rows) x n
+    for a, i in enumerate(rows):
+        krow = krow_fn(i)
+        # (L L^T)_ij for the sampled j: needs row j of L as well -> use pairs inside `rows`
+        for b, j in enumerate(rows):
+            if j > i:
+                continue
+            got = float(Lr[a, : j + 1] @ Lr[b, : j + 1])
+            assert abs(got - krow[j]) <= 1e-10 * max(1.0, abs(krow[j])), (i, j, got, krow[j])
+        # ... and the row norm: (L L^T)_ii = K_ii
+        assert abs(float(Lr[a] @ Lr[a]) - krow[i]) <= 1e-10 * krow[i]
+    d = g.L_diag()
+    assert np.all(d > 0)
+    logdet = 2.0 * float(np.log(d).sum())
+    lml_host = -0.5 * n * math.log(2 * math.pi) - 0.5 * logdet - 0.5 * float(y @ g.Alpha)
+    assert abs(lml_host - lml) <= 1e-9 * abs(lml), (lml_host, lml)
+
+
 def test_config3_full_size_properties(gpmod):
     """BASELINE config 3 (N=16384, D=8, RBF + white noise, fp64) at FULL size through
     size-independent properties (the oracle does not finish in seconds at this N):
@@ -374,6 +401,13 @@ def test_config3_full_size_properties(gpmod):
         krow = c * np.exp(-0.5 * r2)
         krow[i] += s2
         assert abs(krow @ alpha - y[i]) <= 1e-8 * max(1.0, np.abs(krow * alpha).sum()), i
+    # 1b. the factor itself and the log-determinant behind the LML value
+
+    def krow3(i):
+        kr = c * np.exp(-0.5 * ((X[i] - X) ** 2).sum(1) / (l * l))
+        kr[i] += s2
+        return kr
+    _factor_check(g, y, krow3, lml, rng)
     # 2. directional derivative
     v = rng.normal(size=3)
     v /= np.linalg.norm(v)
@@ -428,6 +462,12 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
         krow = krow_fn(i, X)
         krow[i] += s2
         assert abs(krow @ alpha - y[i]) <= 1e-8 * max(1.0, np.abs(krow * alpha).sum()), i
+
+    def krow_noise(i):
+        kr = krow_fn(i, X)
+        kr[i] += s2
+        return kr
+    _factor_check(g, y, krow_noise, lml, rng, nrows=4)
     v = rng.normal(size=len(x))
     v /= np.linalg.norm(v)
     h = 1e-4
