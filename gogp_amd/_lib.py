@@ -24,7 +24,15 @@ _i64 = ctypes.c_int64
 _h = ctypes.c_void_p
 _descp = ctypes.POINTER(CDesc)
 #: callback types of the sharded evaluation (include/gogp_hip.h)
-BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+GOGP_UNIQUE_ID_BYTES = 128
+
+
+class CXfer(ctypes.Structure):
+    _fields_ = [("peer", ctypes.c_int32), ("is_send", ctypes.c_int32), ("buf", ctypes.c_void_p),
+                ("bytes", ctypes.c_int64)]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(CXfer), ctypes.c_int32)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                 ctypes.c_int64)
 SYMBOLS = [
@@ -48,10 +56,14 @@ SYMBOLS = [
     ("gogp_get_factor_rows", ctypes.c_int, [_h, ctypes.POINTER(_i64), _i64, _dp]),
     ("gogp_get_factor_diag", ctypes.c_int, [_h, _dp]),
     ("gogp_set_factor", ctypes.c_int, [_h, _dp, _dp, _dp, _dp]),
-    ("gogp_dist_staging_bytes", _i64, [_i64]),
-    ("gogp_dist_setup", ctypes.c_int,
-     [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-      ctypes.c_void_p, _i64]),
+    ("gogp_dist_grid", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    ("gogp_dist_unique_id", ctypes.c_int, [ctypes.c_void_p]),
+    ("gogp_dist_init_rccl", ctypes.c_int,
+     [_h, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    ("gogp_dist_init_callbacks", ctypes.c_int,
+     [_h, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+      ctypes.c_void_p]),
+    ("gogp_dist_local_bytes", _i64, [_h]),
     ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
     ("gogp_profile_read_aux", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.POINTER(_i64)]),
@@ -113,6 +125,16 @@ def lib() -> ctypes.CDLL:
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(gogp_amd has no CPU fallback)" % LIB_PATH)
+        # PyTorch's wheel bundles its own copies of the HIP runtime and RCCL whose NEEDED names
+        # lack the version suffix: if it is imported AFTER this library, the loader does not
+        # match them with the already-loaded /opt/rocm copies and the process ends up with two
+        # HIP runtimes (observed: heap corruption at exit).  Where torch exists, load it first;
+        # this library then binds to the copies torch loaded (same SONAMEs).  Hosts without
+        # torch (the C++ / Go bindings) are not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         # RTLD_GLOBAL: libgogp_testhooks.so resolves the internal launchers against it
         L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, restype, argtypes in SYMBOLS:

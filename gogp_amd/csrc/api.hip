@@ -172,6 +172,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->s) (void)hipStreamSynchronize(h->s);
+  gogp_dist_destroy(h);
   free_n_buffers(h);
   free_m_buffers(h);
   (void)hipFree(h->scalars);
@@ -275,7 +276,11 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   // replaced or re-filled
   for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_pending = h->alpha_pending = false;
-  int rc = ensure_n(h, n);
+  if (h->dist) {
+    const int rcs = gogp_dist_sync(h);
+    if (rcs != GOGP_OK) return rcs;
+  }
+  int rc = h->dist ? gogp_dist_ensure_n(h, n) : ensure_n(h, n);
   if (rc != GOGP_OK) return rc;
   h->have_data = true;
   if (n == 0) return GOGP_OK;
@@ -298,7 +303,7 @@ extern "C" int gogp_set_data_device(gogp_handle *h, const double *dX, const doub
 }
 
 // ---- parameters ---------------------------------------------------------------------------
-static int upload_params(gogp_handle *h) {
+int gogp_upload_params(gogp_handle *h) {
   DevParams &p = *h->hostP;
   const gogp_desc &d = h->desc;
   memset(&p, 0, sizeof p);
@@ -416,7 +421,7 @@ static int factorize(gogp_handle *h, bool eager) {
   h->alpha_pending = false;
   h->trtri_done = false;
   h->notpd = -1;
-  int rc = upload_params(h);
+  int rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
   if (eager) {
     rc = ensure_y(h);
@@ -610,7 +615,7 @@ extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
     h->factored = false;
     return GOGP_OK;
   }
-  rc = h->dist ? dist_factorize(h, false) : factorize(h, false);
+  rc = h->dist ? gogp_dist_factorize(h, false) : factorize(h, false);
   if (rc != GOGP_OK) return rc;
   rc = ensure_alpha(h);  // gp/gp.go:232-236
   if (rc != GOGP_OK) return rc;
@@ -632,7 +637,7 @@ static int observe_theta(gogp_handle *h, const double *x, double *lml) {
     if (lml) *lml = 0.0;
     return GOGP_OK;
   }
-  rc = h->dist ? dist_factorize(h, true)
+  rc = h->dist ? gogp_dist_factorize(h, true)
                : factorize(h, h->eager != 0);  // gp/gp.go:402 (with gradient preparation)
   if (rc != GOGP_OK) return rc;
   h->observed = true;
@@ -717,7 +722,7 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
     return fail(h, GOGP_EARG, "sharded evaluation: the full Observe form is not supported");
   if (!h->grad_valid && h->dist) {
     // sharded: every rank reduces its own tiles of K^-1, one all-reduce of the slot sums
-    int rc = dist_gradient_sums(h, h->hscal + 16);
+    int rc = gogp_dist_gradient_sums(h, h->hscal + 16);
     if (rc != GOGP_OK) return rc;
   } else if (!h->grad_valid) {
     int rc = compute_kinv(h);
@@ -794,6 +799,7 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   if (m == 0) return GOGP_OK;
   if (h->n > 0 && !h->factored) return fail(h, GOGP_ESTATE, "Produce: nothing absorbed");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->dist && h->n > 0) return gogp_dist_produce(h, Z, m, mu, sigma);
   const int64_t mpad = ((m + TILE - 1) / TILE) * TILE;
   int rc = ensure_m(h, m, mpad);
   if (rc != GOGP_OK) return rc;
@@ -802,7 +808,7 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
          *dsig = h->pvec + 3 * mpad;
   if (h->n == 0 || !h->factored) {
     // no observations: parameters may not have been uploaded yet
-    rc = upload_params(h);
+    rc = gogp_upload_params(h);
     if (rc != GOGP_OK) return rc;
   }
   HIPCHK(h, hipMemcpyAsync(h->dZ, Z, (size_t)m * h->D * sizeof(double), hipMemcpyHostToDevice, s));
@@ -865,6 +871,7 @@ extern "C" int gogp_get_factor(gogp_handle *h, double *Lout) {
   if (!h || (h->n > 0 && !Lout)) return GOGP_EARG;
   if (h->n == 0) return GOGP_OK;
   if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
+  if (h->dist) return fail(h, GOGP_ESTATE, "L: not available on a sharded handle (tiles live on their ranks)");
   HIPCHK(h, hipSetDevice(h->device));
   double *tmp = nullptr;
   HIPCHK(h, hipMalloc(&tmp, (size_t)h->n * h->n * sizeof(double)));
@@ -915,6 +922,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
                                const double *alpha) {
   if (!h || !theta_simil || (h->nn > 0 && !theta_noise)) return fail(h, GOGP_EARG, "set_factor: NULL");
   if (!h->have_data) return fail(h, GOGP_ESTATE, "set_factor: no data");
+  if (h->dist) return fail(h, GOGP_ESTATE, "set_factor: not available on a sharded handle");
   if (h->n > 0 && (!Lin || !alpha)) return fail(h, GOGP_EARG, "set_factor: NULL");
   HIPCHK(h, hipSetDevice(h->device));
   int rc = set_theta_natural(h, theta_simil, theta_noise);
@@ -925,7 +933,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_done = h->trtri_pending = false;
   if (h->n == 0) return GOGP_OK;
-  rc = upload_params(h);
+  rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
   hipStream_t s = h->s;
   const int64_t n = h->n, npad = h->npad;

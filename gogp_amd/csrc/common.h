@@ -44,11 +44,29 @@ struct GemmProfile {
   int64_t launches = 0;
 };
 
-// Ownership filter for the tile kernel in a sharded evaluation (see GemmArgs):
-// n ranks, this rank r, tiles_per_sp 128-wide tile columns per super-panel, col0 =
-// global index of the launch's first 128-wide tile column.
-struct GemmOwn {
-  int n, r, tiles_per_sp, col0;
+// Tile filter of the tile kernel in a sharded (2-D block-cyclic) evaluation (GemmArgs in
+// dgemm.hip): the launch covers LOCAL 128-tiles starting at local row / column block
+// rblk0 / cblk0 (a distribution block = 2^tpb_shift tiles); this rank sits at (pr, pc) of
+// the Pr x Pc process grid.  rule 1: keep the tiles of the GLOBAL lower triangle; rule 2:
+// the same, and tiles of global row block beta0 overwrite C (beta = 0) while the others
+// accumulate (beta = 1): the rank-k updates of K^-1 = Y Y^T.
+struct GemmGrid {
+  int rule = 0, tpb_shift = 0, rblk0 = 0, cblk0 = 0, pr = 0, Pr = 1, pc = 0, Pc = 1, beta0 = -1;
+};
+
+// Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of
+// nb = 2^nb_shift rows / columns; local row block bi of the rank at grid row pr is global block
+// bi * Pr + pr (columns: pc, Pc).
+struct BlockMap {
+  int nb_shift = 9, pr = 0, Pr = 1, pc = 0, Pc = 1;
+  __host__ __device__ long grow(long lrow) const {
+    const long nbm = (1L << nb_shift) - 1;
+    return ((((lrow >> nb_shift) * Pr + pr)) << nb_shift) + (lrow & nbm);
+  }
+  __host__ __device__ long gcol(long lcol) const {
+    const long nbm = (1L << nb_shift) - 1;
+    return ((((lcol >> nb_shift) * Pc + pc)) << nb_shift) + (lcol & nbm);
+  }
 };
 
 // ---- launchers implemented in the .hip files ------------------------------
@@ -64,10 +82,15 @@ enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2,
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
                      double alpha, const double *A, int64_t lda, const double *B,
                      int64_t ldb, double beta, double *C, int64_t ldc,
-                     GemmProfile *prof, const GemmOwn *own = nullptr);
+                     GemmProfile *prof, const GemmGrid *grid = nullptr);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
+// Local tiles (mrows x ncols) of a 2-D block-cyclic Gram matrix: tiles of the global lower
+// triangle get kernel values (identity padding for rows >= n), distribution blocks strictly
+// above the diagonal are zero-filled (the work area R of the triangular inverse).
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld);
 void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
                              const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
                              int64_t wcols);
@@ -96,6 +119,9 @@ void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double
 // failure wins).
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+// the same with Dinv written into a 256x256 sub-block of a matrix of leading dimension 512
+void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                          double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld);
@@ -106,7 +132,14 @@ int grad_reduce_blocks(int64_t npad);
 // fused gradient reduction over lower tiles of Kinv; out: NACC doubles
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
-                        int64_t npad, double *partials, double *out, int own_n = 0, int own_r = 0);
+                        int64_t npad, double *partials, double *out);
+// the same over the LOCAL tiles (mrows x ncols, leading dimension ld) of a 2-D block-cyclic
+// K^-1: tiles of the global lower triangle only; `partials` needs grad_reduce_blocks_local
+int grad_reduce_blocks_local(int64_t mrows, int64_t ncols);
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out);
 
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}
@@ -124,6 +157,19 @@ void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const doubl
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
+// helpers of the sharded evaluation (solve.hip)
+void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
+                         int n);
+void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
+                        int first, int stride);
+void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
+                       double *out);
+void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out);
+void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
+                         double *acc);
+void launch_sumsq_info(hipStream_t s, const double *z, int64_t n, const long long *info, double *out);
+void launch_info_to_double(hipStream_t s, const long long *info, double *out);
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n,
                           double *out);
 

@@ -43,12 +43,15 @@ struct GemmArgs {
   double alpha, beta;
   // GEMM_LAUUM only: the K range of tile (ti,tj) is [ti*BT, kend)
   int kend;
-  // Ownership filter of a sharded evaluation (own_n <= 1: none).  RECT / LOWER: a tile
-  // is computed iff its block column belongs to this rank, i.e.
-  // ((own_col0 + tj) / own_tps) % own_n == own_r  (tile columns counted in units of
-  // this kernel's tile, own_tps tiles per super-panel).  LAUUM: iff ti % own_n == own_r.
-  int own_n, own_r, own_tps, own_col0;
   int trap;  // GEMM_TRAP: skip tiles of strictly upper 256-blocks
+  // Tile filter of a sharded (2-D block-cyclic) evaluation, GEMM_RECT only; rule 0: none.
+  // The launch covers LOCAL tiles; local tile (ti, tj) lies in the distribution block
+  //   global row block  gI = (rblk0 + (ti >> tpb_shift)) * Pr + pr,
+  //   global col block  gJ = (cblk0 + (tj >> tpb_shift)) * Pc + pc      (common.h: GemmGrid)
+  // rule 1/2: keep the tile iff it belongs to the lower triangle of the GLOBAL matrix (gI > gJ,
+  // or gI == gJ and the tile is on/below the diagonal of that block); rule 2 additionally
+  // overwrites (beta = 0) the tiles of row block gI == beta0 and accumulates into the others.
+  int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -109,15 +112,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     tj = t - ti * (ti + 1) / 2;
   }
-  if (g.own_n > 1) {  // workgroup-uniform early exit for tiles of other ranks
-    if (MODE == GEMM_LAUUM) {
-      if (ti % g.own_n != g.own_r) return;
-    } else if (((g.own_col0 + tj) / g.own_tps) % g.own_n != g.own_r) {
-      return;
-    }
+  double beta = g.beta;
+  if (MODE == GEMM_RECT && g.rule) {  // workgroup-uniform early exit: tiles of the global upper triangle
+    const int gI = (g.rblk0 + (ti >> g.tpb_shift)) * g.Pr + g.pr;
+    const int gJ = (g.cblk0 + (tj >> g.tpb_shift)) * g.Pc + g.pc;
+    const int msk = (1 << g.tpb_shift) - 1;
+    if (gI < gJ || (gI == gJ && (ti & msk) < (tj & msk))) return;
+    if (g.rule == 2) beta = (gI == g.beta0) ? 0.0 : 1.0;
   }
   int kbeg = 0, nkt = g.nkt;
-  const double beta = g.beta;
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
     nkt = (g.kend - kbeg) / GEMM_BK;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
                      const double *A, int64_t lda, const double *B, int64_t ldb,
-                     double beta, double *C, int64_t ldc, GemmProfile *prof, const GemmOwn *own) {
+                     double beta, double *C, int64_t ldc, GemmProfile *prof, const GemmGrid *grid) {
   if (mt <= 0 || nt <= 0 || K <= 0) return;
   GemmArgs g;
   g.A = A;
@@ -246,10 +249,20 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.alpha = alpha;
   g.beta = beta;
   g.kend = (int)K;
-  g.own_n = own ? own->n : 0;
-  g.own_r = own ? own->r : 0;
-  g.own_tps = own ? own->tiles_per_sp : 1;
-  g.own_col0 = own ? own->col0 : 0;
+  g.rule = 0;
+  g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
+  g.Pr = g.Pc = 1;
+  if (grid && grid->rule) {
+    g.rule = grid->rule;
+    g.tpb_shift = grid->tpb_shift;
+    g.rblk0 = grid->rblk0;
+    g.cblk0 = grid->cblk0;
+    g.pr = grid->pr;
+    g.Pr = grid->Pr;
+    g.pc = grid->pc;
+    g.Pc = grid->Pc;
+    g.beta0 = grid->beta0;
+  }
   int ntiles;
   double flops;
   g.trap = 0;
@@ -262,6 +275,16 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   } else if (mode == GEMM_RECT) {
     ntiles = mt * nt;
     flops = 2.0 * (double)mt * TILE * (double)nt * TILE * (double)K;
+    if (g.rule) {  // count the tiles the filter keeps
+      const int tpb = 1 << g.tpb_shift;
+      long kept = 0;
+      for (int bi = 0; bi < mt / tpb; ++bi)
+        for (int bj = 0; bj < nt / tpb; ++bj) {
+          const int gI = (g.rblk0 + bi) * g.Pr + g.pr, gJ = (g.cblk0 + bj) * g.Pc + g.pc;
+          kept += gI > gJ ? (long)tpb * tpb : (gI == gJ ? (long)tpb * (tpb + 1) / 2 : 0);
+        }
+      flops = 2.0 * (double)kept * TILE * TILE * (double)K;
+    }
   } else {
     ntiles = mt * (mt + 1) / 2;
     if (mode == GEMM_LOWER) {
@@ -293,8 +316,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   if (small) {
     g.mt = mt * 2;
     g.nt = nt * 2;
-    g.own_tps *= 2;  // ownership counted in 64-wide tile columns
-    g.own_col0 *= 2;
+    g.tpb_shift += 1;  // distribution blocks counted in 64-wide tiles
     const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)
       hipLaunchKernelGGL((dgemm_nt_kernel<GEMM_RECT, 64, 4>), dim3(n64), dim3(256), 0, s, g);

@@ -445,7 +445,7 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const d
     if (STAMP && tid == 0) stamps[k] = __builtin_amdgcn_s_memtime();    \
   } while (0)
 
-template <bool DO_POTRF, bool STAMP>
+template <bool DO_POTRF, bool STAMP, int LDD>
 __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_s,
                                              const double *__restrict__ A, long ld,
                                              double *__restrict__ Lout, long ldl,
@@ -530,9 +530,9 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
 #pragma unroll 2
     for (int idx = tid; idx < 128 * 64; idx += NT) {
       const int i = idx >> 6, cc = (idx & 63) * 2;
-      *reinterpret_cast<f64x2 *>(Dinv + (off + i) * 256 + off + cc) =
+      *reinterpret_cast<f64x2 *>(Dinv + (off + i) * LDD + off + cc) =
           *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
-      if (half == 0) *reinterpret_cast<f64x2 *>(Dinv + i * 256 + 128 + cc) = (f64x2){0.0, 0.0};
+      if (half == 0) *reinterpret_cast<f64x2 *>(Dinv + i * LDD + 128 + cc) = (f64x2){0.0, 0.0};
     }
     __syncthreads();
     GOGP_STAMP(half * 8 + 5);
@@ -575,18 +575,20 @@ __device__ __forceinline__ void diag256_body(double *S, double *G, double *rinv_
       for (int v = 0; v < 4; ++v)
         S[(GOGP_RT(m) * 16 + fk + 4 * v) * SLD + GOGP_CT(n) * 16 + fr] = c[m][n][v];
   __syncthreads();
-  wg_gemm128<false, TRI_B>(c, S, G, Dinv, 256, tid);  // U * X00
+  wg_gemm128<false, TRI_B>(c, S, G, Dinv, LDD, tid);  // U * X00
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        Dinv[(128 + GOGP_RT(m) * 16 + fk + 4 * v) * 256 + GOGP_CT(n) * 16 + fr] = -c[m][n][v];
+        Dinv[(128 + GOGP_RT(m) * 16 + fk + 4 * v) * LDD + GOGP_CT(n) * 16 + fr] = -c[m][n][v];
   GOGP_STAMP(18);
 }
 
-template <bool DO_POTRF, bool STAMP>
+// LDD: leading dimension of Dinv (256: a block of its own; 512: a sub-block of the 512x512
+// tile inverse of the sharded path)
+template <bool DO_POTRF, bool STAMP, int LDD>
 __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ A, long ld,
                                                        double *__restrict__ Lout, long ldl,
                                                        double *__restrict__ Dinv, long row0,
@@ -595,18 +597,27 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
   __shared__ __attribute__((aligned(16))) double S[128 * SLD];
   __shared__ __attribute__((aligned(16))) double G[GSIZE];
   __shared__ double rinv_s[8 * 16];  // per-wave scratch of base16
-  diag256_body<DO_POTRF, STAMP>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, stamps);
+  diag256_body<DO_POTRF, STAMP, LDD>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, stamps);
 }
 
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
-  hipLaunchKernelGGL((diag256_kernel<true, false>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
+  hipLaunchKernelGGL((diag256_kernel<true, false, 256>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
                      (long)ldl, Dinv, (long)row0, (long)nvalid, info,
                      (unsigned long long *)nullptr);
 }
 
+#ifndef GOGP_BUILD_TESTHOOKS
+void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                          double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
+  hipLaunchKernelGGL((diag256_kernel<true, false, 512>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
+                     (long)ldl, Dinv, (long)row0, (long)nvalid, info,
+                     (unsigned long long *)nullptr);
+}
+#endif
+
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv) {
-  hipLaunchKernelGGL((diag256_kernel<false, false>), dim3(1), dim3(NT), 0, s, L, (long)ld,
+  hipLaunchKernelGGL((diag256_kernel<false, false, 256>), dim3(1), dim3(NT), 0, s, L, (long)ld,
                      (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
                      (unsigned long long *)nullptr);
 }
@@ -615,7 +626,7 @@ void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double 
 // diagnostic: run the stamped build once on a device-resident 256x256 block
 void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
                             long long *info, unsigned long long *stamps) {
-  hipLaunchKernelGGL((diag256_kernel<true, true>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
+  hipLaunchKernelGGL((diag256_kernel<true, true, 256>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
                      Dinv, 0L, 256L, info, stamps);
 }
 #endif

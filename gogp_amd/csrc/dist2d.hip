@@ -1,0 +1,734 @@
+// dist2d.hip -- ONE evaluation sharded over several GPUs: 2-D block-cyclic layout.
+//
+// Reference counterpart: none.  gp.GP.absorb / Gradient run in one process
+// (goroutines only, gp/gp.go:165-213, :436-470); this file distributes the same
+// mathematics (Gram build gp/gp.go:109-156, Cholesky :228, alpha :232-236, LML :244-253,
+// gradient :418-499) over a Pr x Pc grid of GPUs, one process per GPU.
+//
+// Layout.  nb = 512 (two 256-wide panels of the single-GPU sweep).  The padded matrix has
+// NB = npad / nb block rows / columns, npad a multiple of nb * Pc (Pr divides Pc).  Tile (I, J)
+// lives on the rank at grid position (I mod Pr, J mod Pc); rank = pr * Pc + pc.  Per rank:
+//   A    (mloc*nb) x (nloc*nb) row-major, mloc = NB/Pr, nloc = NB/Pc: its tiles of K.  Tiles of
+//        the global lower triangle: Gram matrix -> destroyed by the trailing updates -> finally
+//        K^-1.  Tiles of strictly upper blocks: R, the right-hand side of the triangular inverse.
+//   Lch  nloc chunks of (mloc*nb) x nb (leading dimension nb): chunk bj = this rank's tiles of
+//        block column bj*Pc + pc of L.  A chunk is contiguous, so the tiles a process row needs
+//        travel without packing.
+//   Ych  the same for Y = L^-T (upper triangular: chunk P holds row blocks <= P).
+//   Dinv NB inverses (nb x nb) of the diagonal tiles of L, replicated.
+//   four pairs of panel buffers (two steps in flight): the tiles of the current L / Y panel
+//        this rank needs for its tile ROWS (Lrow, Yrow: mloc*nb x nb) and for its tile COLUMNS
+//        (Lcol, Ycol: nloc*nb x nb).
+//
+// Step P (block column P; kr = P mod Pr, kc = P mod Pc):
+//   1. rank (kr, kc) factors the diagonal tile (two 256-blocks on the one-workgroup kernel +
+//      three small products) and inverts it; the inverse goes to every rank            [D_P]
+//   2. process column kc: L[I, P] = A[I, P] inv(L_PP)^T for its tile rows I > P  (one GEMM)
+//   3. exchange [L_P]: every rank of process column kc sends its chunk to the ranks of its
+//      process ROW (they share its tile rows), and the tiles J = pc' (mod Pc) of it to the
+//      ranks (pr' != pr, pc') whose tile COLUMNS they are.  Because Pr divides Pc all tiles a
+//      rank needs for its columns come from ONE sender, (pc mod Pr, kc); ranks with
+//      pc mod Pr == pr find them inside their row chunk.  Direct peer sends, no ring: on the
+//      fully connected xGMI mesh every pair has its own link.
+//   4. trailing update A[I, J] -= L[I, P] L[J, P]^T of the local tiles with I >= J > P on
+//      MFMA (dgemm.hip, tile filter rule 1); the next panel's block column first, on the
+//      chain stream (look-ahead), the rest on the bulk stream.
+//   5. process column kc: Y[I, P] = R[I, P] inv(L_PP)^T (I < P), Y[P, P] = inv(L_PP)^T;
+//      z_P += Y[I, P]^T y_I (partial sums of z = L^-1 y = Y^T y)
+//   6. exchange [Y_P], same pattern as 3 with the tile rows / columns <= P
+//   7. R[I, J] -= Y[I, P] L[J, P]^T (I <= P < J) and, for the gradient,
+//      K^-1[I, J] (+)= Y[I, P] Y[J, P]^T (J <= I <= P; tile filter rule 2)
+// End: one all-reduce gives z, the log-determinant and the failure flags; alpha = Y z from the
+// local chunks and a second all-reduce; LML on the host.  Gradient: fused reduction over the
+// local tiles of K^-1 (grad.hip) and one all-reduce of the slot sums.
+//
+// Streams: sp chain (diagonal tile, panel solve, look-ahead update), s bulk trailing update,
+// st chain of the inverse, s2 its bulk updates, sc communication.  With the RCCL transport
+// nothing synchronises with the host inside the sweep.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "comm.h"
+#include "handle.h"
+
+using namespace gogp;
+
+namespace gogp {
+
+struct Dist2D {
+  int rank = 0, nranks = 1, Pr = 1, Pc = 1, pr = 0, pc = 0;
+  int nb = 512, tpb = 4, tpb_shift = 2, nb_shift = 9;
+  int NB = 0, mloc = 0, nloc = 0;
+  Transport *tr = nullptr;
+  hipStream_t sc = nullptr;
+  double *A = nullptr, *Lch = nullptr, *Ych = nullptr, *Dinv = nullptr;
+  double *Lrow[2] = {nullptr, nullptr}, *Lcol[2] = {nullptr, nullptr};
+  double *Yrow[2] = {nullptr, nullptr}, *Ycol[2] = {nullptr, nullptr};
+  double *pack = nullptr;   // send staging of the strided column pieces
+  double *scr = nullptr;    // 2 x 256 x 256 scratch of the diagonal tile
+  double *yloc = nullptr;   // y at the local rows
+  double *red = nullptr;    // [z (npad) | logdet | failing pivot + 1 of every rank]
+  double *ared = nullptr;   // alpha partial sums (npad)
+  double *gpart = nullptr;
+  int64_t cap_npad = 0;
+  int64_t bytes = 0;
+  int ldA() const { return nloc * nb; }
+  double *lchunk(int bj) const { return Lch + (size_t)bj * mloc * nb * nb; }
+  double *ychunk(int bj) const { return Ych + (size_t)bj * mloc * nb * nb; }
+  int rank_of(int r, int c) const { return r * Pc + c; }
+  BlockMap map() const {
+    BlockMap m;
+    m.nb_shift = nb_shift;
+    m.pr = pr;
+    m.Pr = Pr;
+    m.pc = pc;
+    m.Pc = Pc;
+    return m;
+  }
+};
+
+}  // namespace gogp
+
+// number of local blocks b (global index b*Pn + p) with global index <= P
+static inline int first_gt(int P, int p, int Pn) { return P >= p ? (P - p) / Pn + 1 : 0; }
+
+enum { EDIAG = 0, ED = 1, EPANEL = 2, EL = 3, EUPD = 4, ELA = 5, EYCH = 6, EY = 7, ERUPD = 8, ERLA = 9,
+       ENEV = 10 };
+static inline size_t E(int P, int k) { return EV_BASE + (size_t)ENEV * P + k; }
+static inline void rec(gogp_handle *h, size_t i, hipStream_t s) { (void)hipEventRecord(ev(h, i), s); }
+static inline void wait(gogp_handle *h, hipStream_t s, size_t i) { (void)hipStreamWaitEvent(s, ev(h, i), 0); }
+
+static void dist_free_n(Dist2D *d) {
+  for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Lrow[0], d->Lrow[1], d->Lcol[0], d->Lcol[1],
+                    d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack, d->yloc, d->red, d->ared,
+                    d->gpart})
+    (void)hipFree(p);
+  d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = nullptr;
+  for (int i = 0; i < 2; ++i) d->Lrow[i] = d->Lcol[i] = d->Yrow[i] = d->Ycol[i] = nullptr;
+  d->cap_npad = 0;
+  d->bytes = 0;
+}
+
+void gogp_dist_destroy(gogp_handle *h) {
+  Dist2D *d = h->dist;
+  if (!d) return;
+  if (d->sc) (void)hipStreamSynchronize(d->sc);
+  dist_free_n(d);
+  (void)hipFree(d->scr);
+  delete d->tr;
+  if (d->sc) (void)hipStreamDestroy(d->sc);
+  delete d;
+  h->dist = nullptr;
+}
+
+int gogp_dist_sync(gogp_handle *h) {
+  if (h->dist && h->dist->sc) HIPCHK(h, hipStreamSynchronize(h->dist->sc));
+  return GOGP_OK;
+}
+
+extern "C" int gogp_dist_grid(int nranks, int *prow, int *pcol) {
+  if (nranks < 1 || !prow || !pcol) return GOGP_EARG;
+  int best = 1;
+  for (int r = 1; r * r <= nranks; ++r)
+    if (nranks % r == 0 && (nranks / r) % r == 0) best = r;
+  *prow = best;
+  *pcol = nranks / best;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_dist_unique_id(void *id128) {
+  if (!id128) return GOGP_EARG;
+  return rccl_unique_id(id128);
+}
+
+extern "C" int64_t gogp_dist_local_bytes(const gogp_handle *h) {
+  return (h && h->dist) ? h->dist->bytes : 0;
+}
+
+static int dist_init_common(gogp_handle *h, int rank, int nranks, int prow, int pcol, Transport *tr) {
+  if (prow < 1 || pcol < 1 || prow * pcol != nranks || pcol % prow != 0 || rank < 0 || rank >= nranks ||
+      nranks > 64) {
+    delete tr;
+    return fail(h, GOGP_EARG, "dist_init: the grid must be Pr x Pc = nranks with Pr dividing Pc");
+  }
+  if (h->dist) gogp_dist_destroy(h);
+  Dist2D *d = new Dist2D();
+  d->rank = rank;
+  d->nranks = nranks;
+  d->Pr = prow;
+  d->Pc = pcol;
+  d->pr = rank / pcol;
+  d->pc = rank % pcol;
+  d->tr = tr;
+  hipError_t e = hipStreamCreateWithFlags(&d->sc, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&d->scr, (size_t)2 * PANEL * PANEL * sizeof(double));
+  h->dist = d;
+  if (e != hipSuccess) {
+    gogp_dist_destroy(h);
+    return fail(h, GOGP_EHIP, "dist_init: HIP allocation failed");
+  }
+  // data loaded before the handle was sharded must be loaded again (other buffers)
+  h->have_data = h->factored = h->observed = h->grad_valid = h->have_kinv = false;
+  return GOGP_OK;
+}
+
+extern "C" int gogp_dist_init_rccl(gogp_handle *h, int rank, int nranks, int prow, int pcol,
+                                   const void *id128) {
+  if (!h || !id128) return GOGP_EARG;
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, GOGP_EHIP, "hipSetDevice failed");
+  std::string err;
+  Transport *tr = make_rccl_transport(rank, nranks, id128, &err);
+  if (!tr) {
+    h->err = err;
+    return GOGP_EHIP;
+  }
+  return dist_init_common(h, rank, nranks, prow, pcol, tr);
+}
+
+extern "C" int gogp_dist_init_callbacks(gogp_handle *h, int rank, int nranks, int prow, int pcol,
+                                        gogp_exchange_fn exchange, gogp_allreduce_fn allreduce,
+                                        void *user) {
+  if (!h || !exchange || !allreduce) return GOGP_EARG;
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, GOGP_EHIP, "hipSetDevice failed");
+  return dist_init_common(h, rank, nranks, prow, pcol,
+                          make_callback_transport(rank, nranks, exchange, allreduce, user));
+}
+
+// ---- data: sizes and buffers of this rank's shard ----------------------------------------------
+#define DMALLOC(ptr, count)                                                     \
+  do {                                                                          \
+    const size_t b_ = (size_t)(count) * sizeof(double);                         \
+    HIPCHK(h, hipMalloc(&(ptr), b_ ? b_ : sizeof(double)));                     \
+    d->bytes += (int64_t)b_;                                                    \
+  } while (0)
+
+int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
+  Dist2D *d = h->dist;
+  const int64_t unit = (int64_t)d->nb * d->Pc;
+  const int64_t npad = n <= 0 ? 0 : ((n + unit - 1) / unit) * unit;
+  h->n = n;
+  h->npad = npad;
+  h->nblk = (int)(npad / TILE);
+  h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
+  h->trtri_done = false;
+  d->NB = (int)(npad / d->nb);
+  d->mloc = d->NB / d->Pr;
+  d->nloc = d->NB / d->Pc;
+  if (npad > d->cap_npad) {
+    // the unsharded N x N buffers are never allocated on a sharded handle
+    for (double **p : {&h->dX, &h->dy, &h->bufA, &h->bufL, &h->bufY, &h->Dinv, &h->z, &h->w, &h->alpha,
+                       &h->gpart}) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+    h->cap_npad = 0;
+    h->cap_y = 0;
+    dist_free_n(d);
+    const size_t nb2 = (size_t)d->nb * d->nb;
+    const size_t mrows = (size_t)d->mloc * d->nb, ncols = (size_t)d->nloc * d->nb;
+    HIPCHK(h, hipMalloc(&h->dX, (size_t)npad * h->D * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
+    d->bytes = (int64_t)((size_t)npad * (h->D + 3) * sizeof(double));
+    DMALLOC(d->A, mrows * ncols);
+    DMALLOC(d->Lch, mrows * ncols);
+    DMALLOC(d->Ych, mrows * ncols);
+    DMALLOC(d->Dinv, (size_t)d->NB * nb2);
+    for (int i = 0; i < 2; ++i) {
+      DMALLOC(d->Lrow[i], mrows * d->nb);
+      DMALLOC(d->Yrow[i], mrows * d->nb);
+      DMALLOC(d->Lcol[i], ncols * d->nb);
+      DMALLOC(d->Ycol[i], ncols * d->nb);
+    }
+    DMALLOC(d->pack, (size_t)(d->Pc / d->Pr) * ncols * d->nb);
+    DMALLOC(d->yloc, mrows);
+    DMALLOC(d->red, (size_t)npad + 1 + d->nranks);
+    DMALLOC(d->ared, (size_t)npad);
+    DMALLOC(d->gpart, (size_t)grad_reduce_blocks_local((int64_t)mrows, (int64_t)ncols) * NACC);
+    d->cap_npad = npad;
+  }
+  return GOGP_OK;
+}
+
+__global__ void gather_rows_kernel(const double *__restrict__ y, double *__restrict__ yloc, long rows,
+                                   BlockMap map) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) yloc[i] = y[map.grow(i)];
+}
+
+// ---- the diagonal tile: factor + inverse of one nb x nb block on the chain stream -----------
+static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d, int bj_d) {
+  const int nb = d->nb, ldA = d->ldA();
+  const size_t nb2 = (size_t)nb * nb;
+  double *Ablk = d->A + (size_t)bi_d * nb * ldA + (size_t)bj_d * nb;
+  double *Lblk = d->lchunk(bj_d) + (size_t)bi_d * nb2;
+  double *Dv = d->Dinv + (size_t)P * nb2;
+  const int64_t row0 = (int64_t)P * nb;
+  GemmProfile *pf = &h->prof;
+  // L_PP = [[L00, 0], [L10, L11]];  inv = [[X00, 0], [-X11 L10 X00, X11]]
+  launch_diag256_ld512(sp, Ablk, ldA, Lblk, nb, Dv, row0, h->n, h->info);
+  double *L10 = Lblk + (size_t)PANEL * nb;
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, Ablk + (size_t)PANEL * ldA, ldA, Dv, nb, 0.0, L10, nb,
+                  pf);
+  launch_dgemm_nt(sp, GEMM_LOWER, 2, 2, PANEL, -1.0, L10, nb, L10, nb, 1.0,
+                  Ablk + (size_t)PANEL * ldA + PANEL, ldA, pf);
+  launch_diag256_ld512(sp, Ablk + (size_t)PANEL * ldA + PANEL, ldA, Lblk + (size_t)PANEL * nb + PANEL, nb,
+                       Dv + (size_t)PANEL * nb + PANEL, row0 + PANEL, h->n, h->info);
+  launch_zero_block(sp, Dv + PANEL, nb, PANEL, PANEL);
+  launch_zero_block(sp, Lblk + PANEL, nb, PANEL, PANEL);
+  double *X00T = d->scr, *WT = d->scr + (size_t)PANEL * PANEL;
+  launch_transpose_sq(sp, Dv, nb, X00T, PANEL, PANEL);
+  // WT = (L10 X00)^T = X00^T L10^T
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, X00T, PANEL, L10, nb, 0.0, WT, PANEL, pf);
+  // X10 = -X11 (L10 X00) = -X11 WT^T
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, -1.0, Dv + (size_t)PANEL * nb + PANEL, nb, WT, PANEL, 0.0,
+                  Dv + (size_t)PANEL * nb, nb, pf);
+  launch_logdet_block(sp, Lblk, nb, row0, h->n, nb, d->red + h->npad);
+}
+
+#define TRCHK(call)                            \
+  do {                                         \
+    std::string e_;                            \
+    int r_ = (call);                           \
+    if (r_ != GOGP_OK) {                       \
+      h->err = "sharded evaluation: " + e_;    \
+      return r_;                               \
+    }                                          \
+  } while (0)
+
+// ---- one sharded evaluation: Gram + Cholesky + triangular inverse (+ K^-1) -------------------
+int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
+  Dist2D *d = h->dist;
+  const int nb = d->nb, tpb = d->tpb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc;
+  const int NB = d->NB, mloc = d->mloc, nloc = d->nloc, ldA = d->ldA();
+  const int q = Pc / Pr;
+  const size_t nb2 = (size_t)nb * nb;
+  const int64_t npad = h->npad;
+  hipStream_t s = h->s, sp = h->sp, st = h->st, s2 = h->s2, sc = d->sc;
+  GemmProfile *pf = &h->prof;
+  // evaluations are host-synchronous at their boundaries on a sharded handle
+  for (hipStream_t qs : {s, sp, st, s2, h->sl, sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  h->trtri_pending = h->alpha_pending = false;
+  h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
+  h->trtri_done = false;
+  h->notpd = -1;
+  int rc = gogp_upload_params(h);  // on h->s
+  if (rc != GOGP_OK) return rc;
+  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), s));
+  HIPCHK(h, hipMemsetAsync(d->red, 0, ((size_t)npad + 1 + d->nranks) * sizeof(double), s));
+  HIPCHK(h, hipMemsetAsync(d->ared, 0, (size_t)npad * sizeof(double), s));
+  const long lrows = (long)mloc * nb;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((lrows + 255) / 256)), dim3(256), 0, s, h->dy,
+                     d->yloc, lrows, d->map());
+  // every rank builds its own tiles of K (X is replicated): no communication for the O(N^2) step;
+  // the strictly upper blocks are zero-filled (R)
+  launch_gram_local(s, h->devP, h->D, h->dX, h->n, (int64_t)mloc * nb, (int64_t)nloc * nb, d->map(), d->A,
+                    ldA);
+  rec(h, EV_GRAM, s);
+  for (hipStream_t qs : {sp, st, s2, sc}) wait(h, qs, EV_GRAM);
+
+  std::vector<XferOp> ops;
+  for (int P = 0; P < NB; ++P) {
+    const int kr = P % Pr, kc = P % Pc;
+    const int bi_d = P / Pr, bj_d = P / Pc;
+    const int bi0 = first_gt(P, pr, Pr);  // local row blocks [0, bi0): global <= P; [bi0, mloc): > P
+    const int bj0 = first_gt(P, pc, Pc);
+    const bool in_col = (pc == kc), in_row = (pr == kr), is_diag = in_col && in_row;
+    const int slot = P & 1;
+    const int diag_rank = d->rank_of(kr, kc);
+    double *Dv = d->Dinv + (size_t)P * nb2;
+    const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);  // I hold tiles of block column P+1
+
+    // ---- 1. diagonal tile -----------------------------------------------------------------
+    if (in_col && P >= 2) wait(h, sp, E(P - 2, EUPD));  // bulk update of step P-2 touched column P
+    if (is_diag) {
+      diag_tile(h, d, sp, P, bi_d, bj_d);
+      rec(h, E(P, EDIAG), sp);
+      wait(h, sc, E(P, EDIAG));
+    }
+    ops.clear();
+    if (d->nranks > 1) {
+      if (is_diag) {
+        for (int r = 0; r < d->nranks; ++r)
+          if (r != d->rank) ops.push_back({r, true, Dv, (int64_t)nb2});
+      } else {
+        ops.push_back({diag_rank, false, Dv, (int64_t)nb2});
+      }
+      TRCHK(d->tr->group(sc, ops, &e_));
+    }
+    rec(h, E(P, ED), sc);
+
+    // ---- 2. panel solve --------------------------------------------------------------------
+    if (in_col) {
+      wait(h, sp, E(P, ED));
+      if (bi0 < mloc)
+        launch_dgemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, 1.0,
+                        d->A + (size_t)bi0 * nb * ldA + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
+                        d->lchunk(bj_d) + (size_t)bi0 * nb2, nb, pf);
+      rec(h, E(P, EPANEL), sp);
+      wait(h, sc, E(P, EPANEL));
+    }
+
+    // ---- 3. exchange of the L panel -----------------------------------------------------------
+    double *Lrow = in_col ? d->lchunk(bj_d) : d->Lrow[slot];
+    double *Lcol = d->Lcol[slot];
+    if (P >= 2)  // the panel buffers of step P-2 are still being read by its updates
+      for (int k : {EUPD, ELA, ERUPD, ERLA}) wait(h, sc, E(P - 2, k));
+    ops.clear();
+    const int64_t cnt_row = (int64_t)(mloc - bi0) * (int64_t)nb2;
+    if (in_col) {
+      for (int c = 0; c < Pc; ++c)
+        if (c != kc) ops.push_back({d->rank_of(pr, c), true, Lrow + (size_t)bi0 * nb2, cnt_row});
+      if (Pr > 1) {
+        int idx = 0;
+        for (int pc2 = pr; pc2 < Pc; pc2 += Pr, ++idx) {  // receivers' grid columns served by me
+          const int bj02 = first_gt(P, pc2, Pc);
+          const int nblk = nloc - bj02;
+          if (nblk <= 0) continue;
+          double *pk = d->pack + (size_t)idx * nloc * nb2;
+          launch_pack_blocks(sc, pk, Lrow, nblk, (int64_t)nb2, bj02 * q + (pc2 - pr) / Pr, q);
+          for (int r2 = 0; r2 < Pr; ++r2)
+            if (r2 != pr) ops.push_back({d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2});
+        }
+      }
+    } else {
+      ops.push_back({d->rank_of(pr, kc), false, Lrow + (size_t)bi0 * nb2, cnt_row});
+    }
+    const int src_r = pc % Pr;  // grid row of the rank holding the tiles of my tile columns
+    if (src_r != pr && nloc - bj0 > 0)
+      ops.push_back({d->rank_of(src_r, kc), false, Lcol + (size_t)bj0 * nb2, (int64_t)(nloc - bj0) * (int64_t)nb2});
+    TRCHK(d->tr->group(sc, ops, &e_));
+    if (src_r == pr)
+      launch_pack_blocks(sc, Lcol + (size_t)bj0 * nb2, Lrow, nloc - bj0, (int64_t)nb2,
+                         bj0 * q + (pc - pr) / Pr, q);
+    rec(h, E(P, EL), sc);
+
+    // ---- 4. trailing update ------------------------------------------------------------------
+    {
+      GemmGrid gg;
+      gg.rule = 1;
+      gg.tpb_shift = d->tpb_shift;
+      gg.pr = pr;
+      gg.Pr = Pr;
+      gg.pc = pc;
+      gg.Pc = Pc;
+      gg.rblk0 = bi0;
+      int cst = bj0;
+      if (next_mine && bi0 < mloc && bj0 < nloc) {
+        // look-ahead: the next panel's block column (local block bj0) on the chain stream
+        wait(h, sp, E(P, EL));
+        if (P >= 1) wait(h, sp, E(P - 1, EUPD));  // bulk update of step P-1 touched it
+        gg.cblk0 = bj0;
+        launch_dgemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, -1.0, Lrow + (size_t)bi0 * nb2, nb,
+                        Lcol + (size_t)bj0 * nb2, nb, 1.0, d->A + (size_t)bi0 * nb * ldA + (size_t)bj0 * nb,
+                        ldA, pf, &gg);
+        cst = bj0 + 1;
+      }
+      rec(h, E(P, ELA), sp);
+      wait(h, s, E(P, EL));
+      if (bi0 < mloc && cst < nloc) {
+        gg.cblk0 = cst;
+        launch_dgemm_nt(s, GEMM_RECT, (mloc - bi0) * tpb, (nloc - cst) * tpb, nb, -1.0,
+                        Lrow + (size_t)bi0 * nb2, nb, Lcol + (size_t)cst * nb2, nb, 1.0,
+                        d->A + (size_t)bi0 * nb * ldA + (size_t)cst * nb, ldA, pf, &gg);
+      }
+      rec(h, E(P, EUPD), s);
+    }
+
+    // ---- 5. column panel P of Y = L^-T -----------------------------------------------------------
+    const int bim = in_row ? bi0 - 1 : bi0;  // local row blocks with global index < P
+    if (in_col) {
+      wait(h, st, E(P, ED));
+      if (P >= 2) wait(h, st, E(P - 2, ERUPD));  // bulk R update of step P-2 touched column P
+      if (bim > 0)
+        launch_dgemm_nt(st, GEMM_RECT, bim * tpb, tpb, nb, 1.0, d->A + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
+                        d->ychunk(bj_d), nb, pf);
+      if (is_diag) launch_transpose_sq(st, Dv, nb, d->ychunk(bj_d) + (size_t)bi_d * nb2, nb, nb);
+      if (bi0 > 0)  // z_P += sum_I Y[I, P]^T y_I over my tile rows
+        launch_chunk_tdot(st, d->ychunk(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->red + (size_t)P * nb);
+      rec(h, E(P, EYCH), st);
+      wait(h, sc, E(P, EYCH));
+    }
+
+    // ---- 6. exchange of the Y panel ------------------------------------------------------------
+    double *Yrow = in_col ? d->ychunk(bj_d) : d->Yrow[slot];
+    double *Ycol = d->Ycol[slot];
+    ops.clear();
+    const int64_t cnt_yrow = (int64_t)bi0 * (int64_t)nb2;
+    if (in_col) {
+      for (int c = 0; c < Pc; ++c)
+        if (c != kc) ops.push_back({d->rank_of(pr, c), true, Yrow, cnt_yrow});
+      if (Pr > 1) {
+        int idx = 0;
+        for (int pc2 = pr; pc2 < Pc; pc2 += Pr, ++idx) {
+          const int nblk = first_gt(P, pc2, Pc);  // tile columns <= P of grid column pc2
+          if (nblk <= 0) continue;
+          double *pk = d->pack + (size_t)idx * nloc * nb2;
+          launch_pack_blocks(sc, pk, Yrow, nblk, (int64_t)nb2, (pc2 - pr) / Pr, q);
+          for (int r2 = 0; r2 < Pr; ++r2)
+            if (r2 != pr) ops.push_back({d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2});
+        }
+      }
+    } else {
+      ops.push_back({d->rank_of(pr, kc), false, Yrow, cnt_yrow});
+    }
+    if (src_r != pr && bj0 > 0)
+      ops.push_back({d->rank_of(src_r, kc), false, Ycol, (int64_t)bj0 * (int64_t)nb2});
+    TRCHK(d->tr->group(sc, ops, &e_));
+    if (src_r == pr) launch_pack_blocks(sc, Ycol, Yrow, bj0, (int64_t)nb2, (pc - pr) / Pr, q);
+    rec(h, E(P, EY), sc);
+
+    // ---- 7. R update (rows <= P, columns > P) and the rank-nb update of K^-1 -----------------------
+    {
+      int cst = bj0;
+      if (next_mine && bi0 > 0 && bj0 < nloc) {
+        wait(h, st, E(P, EY));
+        wait(h, st, E(P, EL));
+        if (P >= 1) wait(h, st, E(P - 1, ERUPD));
+        launch_dgemm_nt(st, GEMM_RECT, bi0 * tpb, tpb, nb, -1.0, Yrow, nb, Lcol + (size_t)bj0 * nb2, nb, 1.0,
+                        d->A + (size_t)bj0 * nb, ldA, pf);
+        cst = bj0 + 1;
+      }
+      rec(h, E(P, ERLA), st);
+      wait(h, s2, E(P, EY));
+      wait(h, s2, E(P, EL));
+      if (bi0 > 0 && cst < nloc)
+        launch_dgemm_nt(s2, GEMM_RECT, bi0 * tpb, (nloc - cst) * tpb, nb, -1.0, Yrow, nb,
+                        Lcol + (size_t)cst * nb2, nb, 1.0, d->A + (size_t)cst * nb, ldA, pf);
+      if (want_kinv && bi0 > 0 && bj0 > 0) {
+        GemmGrid gk;
+        gk.rule = 2;
+        gk.tpb_shift = d->tpb_shift;
+        gk.pr = pr;
+        gk.Pr = Pr;
+        gk.pc = pc;
+        gk.Pc = Pc;
+        gk.rblk0 = 0;
+        gk.cblk0 = 0;
+        gk.beta0 = P;
+        launch_dgemm_nt(s2, GEMM_RECT, bi0 * tpb, bj0 * tpb, nb, 1.0, Yrow, nb, Ycol, nb, 1.0, d->A, ldA, pf,
+                        &gk);
+      }
+      rec(h, E(P, ERUPD), s2);
+    }
+  }
+
+  // ---- z = Y^T y, log-determinant, failure flags: one all-reduce -------------------------------------
+  rec(h, EV_FWD, st);
+  wait(h, sc, EV_FWD);
+  rec(h, EV_W, sp);
+  wait(h, sc, EV_W);
+  launch_info_to_double(sc, h->info, d->red + (size_t)npad + 1 + d->rank);
+  TRCHK(d->tr->allreduce(sc, d->red, npad + 1 + d->nranks, &e_));
+  HIPCHK(h, hipMemcpyAsync(h->z, d->red, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sc));
+  launch_sumsq_info(sc, h->z, h->n, nullptr, h->scalars);
+  // alpha = Y z: partial sums over the local chunks, second all-reduce
+  launch_chunk_alpha(sc, d->Ych, mloc, nloc, nb, d->map(), h->z, d->ared);
+  TRCHK(d->tr->allreduce(sc, d->ared, npad, &e_));
+  HIPCHK(h, hipMemcpyAsync(h->alpha, d->ared, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sc));
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, sizeof(double), hipMemcpyDeviceToHost, sc));
+  HIPCHK(h, hipMemcpyAsync(h->hscal + 1, d->red + npad, (size_t)(1 + d->nranks) * sizeof(double),
+                           hipMemcpyDeviceToHost, sc));
+  HIPCHK(h, hipStreamSynchronize(sc));
+  HIPCHK(h, hipGetLastError());
+  const double zz = h->hscal[0], logdet = h->hscal[1];
+  double first_fail = 0.0;
+  for (int r = 0; r < d->nranks; ++r) {
+    const double v = h->hscal[2 + r];
+    if (v > 0.0 && (first_fail == 0.0 || v < first_fail)) first_fail = v;
+  }
+  if (first_fail != 0.0 || !std::isfinite(logdet) || !std::isfinite(zz)) {
+    for (hipStream_t qs : {s, sp, st, s2}) (void)hipStreamSynchronize(qs);
+    h->notpd = first_fail != 0.0 ? (int64_t)first_fail - 1 : -1;
+    char buf[160];
+    snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)", (long long)h->notpd);
+    h->err = buf;
+    return GOGP_ENOTPD;
+  }
+  h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * zz;  // gp/gp.go:244-253
+  h->factored = true;
+  h->have_alpha = true;
+  h->have_kinv = want_kinv;
+  h->trtri_done = true;
+  return GOGP_OK;
+}
+
+// ---- gradient: fused reduction over the local tiles of K^-1, one all-reduce ------------------------
+int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
+  Dist2D *d = h->dist;
+  if (!h->have_kinv) return fail(h, GOGP_ESTATE, "Gradient: K^-1 was not formed (Absorb?)");
+  hipStream_t s2 = h->s2, sc = d->sc;
+  // the last rank-nb updates of K^-1 run on s2; alpha is final (host-synchronised)
+  launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->A, d->ldA(), h->n,
+                           (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout);
+  rec(h, EV_ALPHA, s2);
+  wait(h, sc, EV_ALPHA);
+  TRCHK(d->tr->allreduce(sc, h->gout, NACC, &e_));
+  HIPCHK(h, hipMemcpyAsync(hacc, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, sc));
+  HIPCHK(h, hipStreamSynchronize(sc));
+  HIPCHK(h, hipGetLastError());
+  return GOGP_OK;
+}
+
+// ---- Produce on a sharded handle -----------------------------------------------------------------
+// gp.GP.Produce (gp/gp.go:258-360) with L never leaving its ranks:  sigma_j^2 = k(z_j, z_j) -
+// |L^-1 k*_j|^2 and L^-1 = Y^T, so with V = Y^T Kstar:  V[P-block, j] = sum_{I <= P} Y[I, P]^T
+// Kstar[I, j].  Every rank forms the partial sums of its own tiles (its chunks of Y against the
+// cross-covariance rows of its tile rows: one NT GEMM per chunk against the transposed chunk),
+// the Pr ranks of a process column add their partials (one exchange), column norms and
+// mu = Kstar^T alpha partial sums meet in one all-reduce of 2 m doubles.
+__global__ void gather_x_kernel(const double *__restrict__ X, const double *__restrict__ a, int D, long n,
+                                long rows, BlockMap map, double *__restrict__ Xloc,
+                                double *__restrict__ aloc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const long g = map.grow(i);
+  for (int k = 0; k < D; ++k) Xloc[i * D + k] = (g < n) ? X[g * D + k] : 0.0;
+  aloc[i] = (g < n) ? a[g] : 0.0;
+}
+
+// dst (cols x rows, ldd) = src (rows x cols, lds)^T; rows, cols multiples of 32
+__global__ __launch_bounds__(256) void transpose_rect_kernel(const double *__restrict__ src, long lds_,
+                                                             double *__restrict__ dst, long ldd, int ntc) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x % ntc, by = blockIdx.x / ntc;  // bx: column tile, by: row tile of src
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = src[(long)(by * 32 + ty + r) * lds_ + bx * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) dst[(long)(bx * 32 + ty + r) * ldd + by * 32 + tx] = tile[tx][ty + r];
+}
+
+__global__ void add_inplace_kernel(double *__restrict__ a, const double *__restrict__ b, long count) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    a[i] += b[i];
+}
+
+__global__ void scale_kernel(double *__restrict__ a, double f, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) a[i] *= f;
+}
+
+int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
+  Dist2D *d = h->dist;
+  if (!h->trtri_done) return fail(h, GOGP_ESTATE, "Produce: no factorisation");
+  const int nb = d->nb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc, mloc = d->mloc, nloc = d->nloc;
+  const int64_t mpad = ((m + TILE - 1) / TILE) * TILE;
+  const int64_t lrows = (int64_t)mloc * nb, lcols = (int64_t)nloc * nb;
+  hipStream_t s = h->s, sc = d->sc;
+  for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  double *dZ = nullptr, *Xloc = nullptr, *aloc = nullptr, *Ks = nullptr, *Yt = nullptr, *Vt = nullptr,
+         *Vr = nullptr, *vec = nullptr;
+  auto cleanup = [&]() {
+    for (double *p : {dZ, Xloc, aloc, Ks, Yt, Vt, Vr, vec}) (void)hipFree(p);
+  };
+#define PMALLOC(ptr, count)                                                              \
+  do {                                                                                   \
+    if (hipMalloc(&(ptr), (size_t)(count) * sizeof(double) + 16) != hipSuccess) {         \
+      cleanup();                                                                         \
+      (void)hipGetLastError();                                                           \
+      return fail(h, GOGP_ENOMEM, "Produce: out of device memory");                      \
+    }                                                                                    \
+  } while (0)
+  PMALLOC(dZ, m * h->D);
+  PMALLOC(Xloc, lrows * h->D);
+  PMALLOC(aloc, lrows);
+  PMALLOC(Ks, mpad * lrows);
+  PMALLOC(Yt, (int64_t)nb * lrows);
+  PMALLOC(Vt, mpad * lcols);
+  if (Pr > 1) PMALLOC(Vr, (int64_t)(Pr - 1) * mpad * lcols);
+  PMALLOC(vec, 4 * mpad);
+  double *prior = vec, *red2 = vec + mpad /* [mu | q] */, *dsig = vec + 3 * mpad;
+  hipError_t e = hipMemcpyAsync(dZ, Z, (size_t)m * h->D * sizeof(double), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(Vt, 0, (size_t)mpad * lcols * sizeof(double), s);
+  if (e == hipSuccess) e = hipMemsetAsync(red2, 0, (size_t)2 * mpad * sizeof(double), s);
+  if (e != hipSuccess) {
+    cleanup();
+    HIPCHK(h, e);
+  }
+  launch_prior(s, h->devP, dZ, m, prior);  // gp/gp.go:269-278
+  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((lrows + 255) / 256)), dim3(256), 0, s, h->dX,
+                     h->alpha, h->D, (long)h->n, (long)lrows, d->map(), Xloc, aloc);
+  // local rows are in increasing global order: the valid ones (global row < n) form a prefix
+  int64_t nvalid = 0;
+  {
+    BlockMap mp = d->map();
+    for (int64_t i = 0; i < lrows; i += nb) {
+      const int64_t g0 = mp.grow(i);
+      if (g0 >= h->n) break;
+      nvalid += (h->n - g0 < nb) ? h->n - g0 : nb;
+    }
+  }
+  // cross-covariance of the test points with my tile rows: Ks[j][lrow] (gp/gp.go:322-332)
+  launch_cross(s, h->devP, h->D, Xloc, nvalid, lrows, dZ, m, mpad, Ks, lrows);
+  launch_rownorm_dot(s, Ks, lrows, aloc, lrows, m, red2, nullptr);  // partial mu = Kstar^T alpha (:335)
+  if (Pc > 1)  // the Pc ranks of a process row hold the same tile rows
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, s, red2, 1.0 / Pc,
+                       (long)mpad);
+  const int mt = (int)(mpad / TILE);
+  for (int bj = 0; bj < nloc; ++bj) {
+    const int P = bj * Pc + pc;
+    const int bi0 = first_gt(P, pr, Pr);
+    if (bi0 <= 0) continue;
+    const int64_t K = (int64_t)bi0 * nb;
+    hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)((K / 32) * (nb / 32))), dim3(256), 0, s,
+                       d->ychunk(bj), (long)nb, Yt, (long)K, nb / 32);
+    launch_dgemm_nt(s, GEMM_RECT, mt, d->tpb, K, 1.0, Ks, lrows, Yt, K, 0.0, Vt + (size_t)bj * nb, lcols,
+                    nullptr);
+  }
+  // add the partial sums of the other ranks of my process column
+  std::vector<XferOp> ops;
+  if (Pr > 1) {
+    rec(h, EV_W, s);
+    wait(h, sc, EV_W);
+    int k = 0;
+    for (int r2 = 0; r2 < Pr; ++r2) {
+      if (r2 == pr) continue;
+      ops.push_back({d->rank_of(r2, pc), true, Vt, mpad * lcols});
+      ops.push_back({d->rank_of(r2, pc), false, Vr + (size_t)k * mpad * lcols, mpad * lcols});
+      ++k;
+    }
+    std::string terr;
+    int rc = d->tr->group(sc, ops, &terr);
+    if (rc != GOGP_OK) {
+      (void)hipStreamSynchronize(sc);
+      cleanup();
+      h->err = "sharded Produce: " + terr;
+      return rc;
+    }
+    rec(h, EV_FWD, sc);
+    wait(h, s, EV_FWD);
+    for (int i = 0; i < Pr - 1; ++i)
+      hipLaunchKernelGGL(add_inplace_kernel, dim3(1024), dim3(256), 0, s, Vt, Vr + (size_t)i * mpad * lcols,
+                         (long)(mpad * lcols));
+  }
+  // |V_j|^2 over my tile columns; every rank of a process column holds the same sums
+  launch_rownorm_dot(s, Vt, lcols, nullptr, lcols, m, nullptr, red2 + mpad);
+  if (Pr > 1)
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, s, red2 + mpad,
+                       1.0 / Pr, (long)mpad);
+  rec(h, EV_W, s);
+  wait(h, sc, EV_W);
+  {
+    std::string terr;
+    int rc = d->tr->allreduce(sc, red2, 2 * mpad, &terr);
+    if (rc != GOGP_OK) {
+      (void)hipStreamSynchronize(sc);
+      cleanup();
+      h->err = "sharded Produce: " + terr;
+      return rc;
+    }
+  }
+  launch_sigma(sc, prior, red2 + mpad, m, dsig);  // gp/gp.go:354-357, unclamped
+  e = hipMemcpyAsync(mu, red2, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, sc);
+  if (e == hipSuccess) e = hipMemcpyAsync(sigma, dsig, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  cleanup();
+  HIPCHK(h, e);
+  HIPCHK(h, hipGetLastError());
+  return GOGP_OK;
+}

@@ -17,11 +17,13 @@ namespace gogp {
 
 constexpr int GR_BLOCKS_MAX = 2048;
 
-template <int ARD_D>
+// LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
+// grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
+template <int ARD_D, bool LOCAL>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
     const double *__restrict__ alpha, const double *__restrict__ Kinv, long ld, long n, int nt,
-    int ntiles, double *__restrict__ partials, int own_n, int own_r) {
+    int ntiles, double *__restrict__ partials, int ntc, BlockMap map) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -41,13 +43,24 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
   for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) ard[q] = 0.0;
 
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > t) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    // sharded evaluation: only the 128-row tile rows of K^-1 this rank computed
-    if (own_n > 1 && ((ti >> 1) % own_n) != own_r) continue;
-    const long r0 = (long)ti * 64, c0 = (long)tj * 64;
+    int ti, tj;
+    long r0, c0, lr0, lc0;
+    if (LOCAL) {
+      ti = t / ntc;
+      tj = t - ti * ntc;
+      lr0 = (long)ti * 64;
+      lc0 = (long)tj * 64;
+      r0 = map.grow(lr0);
+      c0 = map.gcol(lc0);
+      if (c0 > r0) continue;  // workgroup-uniform: tile of the global upper triangle
+    } else {
+      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 > t) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      tj = t - ti * (ti + 1) / 2;
+      lr0 = r0 = (long)ti * 64;
+      lc0 = c0 = (long)tj * 64;
+    }
     __syncthreads();  // previous tile's readers are done
     for (int idx = tid; idx < 64 * D; idx += 256) {
       const int r = idx / D, d = idx - r * D;
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
       const int r = ty * 16 + rr;
       const long gi = r0 + r;
       if (gi < n && gj <= gi) {
-        const double w = ai[r] * ajv - Kinv[gi * ld + gj];
+        const double w = ai[r] * ajv - Kinv[(lr0 + r) * ld + lc0 + tx];
         const double wgt = (gj < gi) ? 2.0 * w : w;
         const double *ri = Ri + r * D;
         simil_grad_accum<ARD_D>(
@@ -125,21 +138,45 @@ int grad_reduce_blocks(int64_t npad) {
 
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out, int own_n,
-                        int own_r) {
+                        int64_t n, int64_t npad, double *partials, double *out) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GR(AD)                                                                      \
-  hipLaunchKernelGGL(grad_reduce_kernel<AD>, dim3(blocks), dim3(256), lds, s, p, X, alpha, Kinv, \
-                     (long)ld, (long)n, nt, ntiles, partials, own_n, own_r)
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap())
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
   else if (ard_dims <= 16) GOGP_LAUNCH_GR(16);
   else if (ard_dims <= 32) GOGP_LAUNCH_GR(32);
   else GOGP_LAUNCH_GR(64);
 #undef GOGP_LAUNCH_GR
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+}
+
+int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
+  const long ntiles = (long)(mrows / 64) * (long)(ncols / 64);
+  return (int)(ntiles < GR_BLOCKS_MAX ? (ntiles > 0 ? ntiles : 1) : GR_BLOCKS_MAX);
+}
+
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out) {
+  const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
+  const int ntiles = nt * ntc;
+  const int blocks = grad_reduce_blocks_local(mrows, ncols);
+  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+#define GOGP_LAUNCH_GRL(AD)                                                                       \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map)
+  if (ard_dims <= 0) GOGP_LAUNCH_GRL(0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8);
+  else if (ard_dims <= 16) GOGP_LAUNCH_GRL(16);
+  else if (ard_dims <= 32) GOGP_LAUNCH_GRL(32);
+  else GOGP_LAUNCH_GRL(64);
+#undef GOGP_LAUNCH_GRL
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
 }
 
@@ -235,9 +272,15 @@ void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
                      (long)ld, nt32);
   const size_t lds = (size_t)(128 * ndim + 64 * 65 + 64) * sizeof(double);
   const dim3 grid((unsigned)(npad / 64));
-#define GOGP_LAUNCH_XG(DM)                                                                   \
-  hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
-                     (long)n, (long)npad, gx)
+  // above 64 KB of dynamic LDS (D > 32) the limit has to be raised explicitly
+#define GOGP_LAUNCH_XG(DM)                                                                     \
+  do {                                                                                         \
+    if (lds > 64 * 1024)                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xgrad_kernel<DM>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+    hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
+                       (long)n, (long)npad, gx);                                               \
+  } while (0)
   if (ndim <= 4) GOGP_LAUNCH_XG(4);
   else if (ndim <= 8) GOGP_LAUNCH_XG(8);
   else if (ndim <= 16) GOGP_LAUNCH_XG(16);

@@ -76,6 +76,53 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
   }
 }
 
+// 2-D block-cyclic variant: rectangular grid over the LOCAL 64x64 tiles, global indices
+// through the block map (see common.h).
+__global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__restrict__ Pp,
+                                                         const double *__restrict__ X, long n,
+                                                         double *__restrict__ Out, long ld, int ntc,
+                                                         BlockMap map) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Ri = sm;
+  double *CjT = sm + 64 * D;
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
+  const long lr0 = (long)ti * 64, lc0 = (long)tj * 64;
+  const long r0 = map.grow(lr0), c0 = map.gcol(lc0);
+  const int tx = tid & 63, ty = tid >> 6;
+  if ((r0 >> map.nb_shift) < (c0 >> map.nb_shift)) {  // strictly upper distribution block: R := 0
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) Out[(lr0 + ty * 16 + rr) * ld + lc0 + tx] = 0.0;
+    return;
+  }
+  if (r0 + 63 < c0) return;  // upper tile inside a diagonal block: never read
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int r = idx / D, d = idx - r * D;
+    Ri[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
+    CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+  }
+  __syncthreads();
+  const long gj = c0 + tx;
+  const double *cj = CjT + tx;
+#pragma unroll 2
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = ty * 16 + rr;
+    const long gi = r0 + r;
+    const double *ri = Ri + r * D;
+    double k;
+    if (gi < n && gj < n) {
+      k = simil_value(
+          P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; });
+      if (gi == gj) k += P.noise_var;
+    } else {
+      k = (gi == gj) ? 1.0 : 0.0;
+    }
+    Out[(lr0 + r) * ld + lc0 + tx] = k;
+  }
+}
+
 __global__ void prior_kernel(const DevParams *__restrict__ Pp, const double *__restrict__ Z,
                              long m, double *__restrict__ prior) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,6 +158,15 @@ void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevP
   if (nr > 0)
     hipLaunchKernelGGL(gram_kernel<false>, dim3(nr * (nr + 1) / 2), dim3(256), lds, s_rest, p, X,
                        (long)n, X, (long)n, K, (long)ld, nt, 0, w);
+}
+
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld) {
+  const int ntr = (int)(mrows / 64), ntc = (int)(ncols / 64);
+  if (ntr <= 0 || ntc <= 0) return;
+  const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
+  hipLaunchKernelGGL(gram_local_kernel, dim3(ntr * ntc), dim3(256), lds, s, p, X, (long)n, K, (long)ld,
+                     ntc, map);
 }
 
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,

@@ -10,6 +10,8 @@
 namespace gogp {
 struct Dist2D;  // dist2d.hip
 }
+using gogp::DevParams;
+using gogp::GemmProfile;
 
 struct gogp_handle {
   gogp_desc desc;
@@ -128,3 +130,12 @@ static inline void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t
   (void)hipStreamWaitEvent(to, e, 0);
 }
 
+
+// ---- sharded evaluation (dist2d.hip) -----------------------------------------------------------
+int gogp_upload_params(gogp_handle *h);            // api.hip: theta -> DevParams on h->s
+void gogp_dist_destroy(gogp_handle *h);
+int gogp_dist_sync(gogp_handle *h);                // drain the communication stream
+int gogp_dist_ensure_n(gogp_handle *h, int64_t n);  // sizes + buffers of this rank's shard
+int gogp_dist_factorize(gogp_handle *h, bool want_kinv);
+int gogp_dist_gradient_sums(gogp_handle *h, double *hacc /* NACC, pinned host */);
+int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma);

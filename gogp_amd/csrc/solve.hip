@@ -352,4 +352,154 @@ void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m
                      (long)m, sigma);
 }
 
+// ---- helpers of the sharded (2-D block-cyclic) evaluation ------------------------------------
+
+// dst (n x n, ldd) = src (n x n, lds)^T, n a multiple of 32
+__global__ __launch_bounds__(256) void transpose_sq_kernel(const double *__restrict__ src, long lds_,
+                                                           double *__restrict__ dst, long ldd, int nt) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x % nt, by = blockIdx.x / nt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = src[(long)(by * 32 + ty + r) * lds_ + bx * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) dst[(long)(bx * 32 + ty + r) * ldd + by * 32 + tx] = tile[tx][ty + r];
+}
+
+void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
+                         int n) {
+  const int nt = n / 32;
+  hipLaunchKernelGGL(transpose_sq_kernel, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
+                     (long)ldd, nt);
+}
+
+// dst block d (blk doubles, contiguous) = src block (first + d * stride), d < nblk
+__global__ __launch_bounds__(256) void pack_blocks_kernel(double *__restrict__ dst,
+                                                          const double *__restrict__ src, long blk,
+                                                          int first, int stride) {
+  const long d = blockIdx.y;
+  const double2 *sp = reinterpret_cast<const double2 *>(src + (long)(first + d * stride) * blk);
+  double2 *dp = reinterpret_cast<double2 *>(dst + d * blk);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < blk / 2; i += (long)gridDim.x * 256)
+    dp[i] = sp[i];
+}
+
+void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
+                        int first, int stride) {
+  if (nblk <= 0) return;
+  hipLaunchKernelGGL(pack_blocks_kernel, dim3(64, (unsigned)nblk), dim3(256), 0, s, dst, src,
+                     (long)blk, first, stride);
+}
+
+// out[c] = sum_{r < rows} chunk[r][c] * v[r]   (chunk rows x nb, leading dimension nb)
+// one workgroup per 64 columns; 4 waves split the rows; fixed-order reduction
+__global__ __launch_bounds__(256) void chunk_tdot_kernel(const double *__restrict__ chunk, long rows,
+                                                         int nb, const double *__restrict__ v,
+                                                         double *__restrict__ out) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double a = 0.0;
+  for (long r = wid; r < rows; r += 4) a += chunk[r * nb + c] * v[r];
+  red[wid][lane] = a;
+  __syncthreads();
+  if (wid == 0) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
+                       double *out) {
+  hipLaunchKernelGGL(chunk_tdot_kernel, dim3(nb / 64), dim3(256), 0, s, chunk, (long)rows, nb, v, out);
+}
+
+// alpha partial of one rank: for every local row (local row block bi, global block
+// gI = bi*Pr + pr) out[global row] = sum over the local chunks bj with gP = bj*Pc + pc >= gI of
+// sum_c Ych[bj][bi][r][c] * z[gP*nb + c].  Ych: nloc chunks of (mloc*nb) x nb.  One wave per row.
+__global__ __launch_bounds__(256) void chunk_alpha_kernel(const double *__restrict__ Ych, int mloc,
+                                                          int nloc, int nb, BlockMap map,
+                                                          const double *__restrict__ z,
+                                                          double *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long lrow = (long)blockIdx.x * 4 + wid;
+  if (lrow >= (long)mloc * nb) return;
+  const int bi = (int)(lrow / nb);
+  const int gI = bi * map.Pr + map.pr;
+  const long chunk_sz = (long)mloc * nb * nb;
+  double s0 = 0.0, s1 = 0.0;
+  for (int bj = 0; bj < nloc; ++bj) {
+    const int gP = bj * map.Pc + map.pc;
+    if (gP < gI) continue;
+    const double *row = Ych + bj * chunk_sz + lrow * nb;
+    const double *zz = z + (long)gP * nb;
+    for (int c = lane * 2; c < nb; c += 128) {
+      const double2 y = *reinterpret_cast<const double2 *>(row + c);
+      const double2 q = *reinterpret_cast<const double2 *>(zz + c);
+      s0 += y.x * q.x;
+      s1 += y.y * q.y;
+    }
+  }
+  double sum = s0 + s1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) out[map.grow(lrow)] = sum;
+}
+
+void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out) {
+  const long rows = (long)mloc * nb;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(chunk_alpha_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc,
+                     nloc, nb, map, z, out);
+}
+
+// acc[0] += sum_{i < nb, row0 + i < n} 2 log L[i][i]   (one diagonal block; single workgroup)
+__global__ __launch_bounds__(256) void logdet_block_kernel(const double *__restrict__ L, long ld,
+                                                           long row0, long n, int nb,
+                                                           double *__restrict__ acc) {
+  __shared__ double red[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (row0 + i < n) a += 2.0 * log(L[(long)i * ld + i]);
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) acc[0] += red[0] + red[1] + red[2] + red[3];
+}
+
+void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
+                         double *acc) {
+  hipLaunchKernelGGL(logdet_block_kernel, dim3(1), dim3(256), 0, s, L, (long)ld, (long)row0, (long)n,
+                     nb, acc);
+}
+
+// out[0] = sum_{i<n} z_i^2 ; out[1] = (double)*info   (single workgroup, fixed order)
+__global__ __launch_bounds__(1024) void sumsq_info_kernel(const double *__restrict__ z, long n,
+                                                          const long long *__restrict__ info,
+                                                          double *__restrict__ out) {
+  __shared__ double red[16];
+  double a = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) a += z[i] * z[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
+    if (info) out[1] = (double)*info;
+  }
+}
+
+void launch_sumsq_info(hipStream_t s, const double *z, int64_t n, const long long *info, double *out) {
+  hipLaunchKernelGGL(sumsq_info_kernel, dim3(1), dim3(1024), 0, s, z, (long)n, info, out);
+}
+
+__global__ void info_to_double_kernel(const long long *__restrict__ info, double *__restrict__ out) {
+  out[0] = (double)*info;
+}
+
+void launch_info_to_double(hipStream_t s, const long long *info, double *out) {
+  hipLaunchKernelGGL(info_to_double_kernel, dim3(1), dim3(1), 0, s, info, out);
+}
+
 }  // namespace gogp

@@ -1,14 +1,18 @@
 """One GP evaluation sharded over several GPUs (one process per GPU).
 
-``ShardedGP`` is a ``gp.GP`` whose Observe / Gradient run the 1-D block-cyclic
-sharded factorisation of libgogp_hip (include/gogp_hip.h, "one evaluation sharded
-over several GPUs").  Every rank constructs it with the SAME kernel, data and
-arguments and calls the SAME methods in the same order (collective semantics);
-every rank gets the same LML, gradient, Alpha and L, so Produce works on any rank.
+``ShardedGP`` is a ``gp.GP`` whose Absorb / Observe / Gradient run the 2-D block-cyclic
+sharded evaluation of libgogp_hip (include/gogp_hip.h, "one evaluation sharded over several
+GPUs"; gogp_amd/csrc/dist2d.hip): the ranks form a Pr x Pc grid, tile (I, J) of the Gram
+matrix lives on rank (I mod Pr, J mod Pc), every rank allocates only its own tiles.  Every
+rank constructs the object with the SAME kernel, data and arguments and calls the SAME
+methods in the same order (collective semantics); every rank gets the same LML, gradient and
+Alpha.
 
-Communication: ``torch.distributed`` -- backend "nccl" (RCCL over xGMI) on a real
-node, "gloo" for rehearsals (several ranks may then share one GPU).  The panel
-broadcast goes through a staging tensor owned here; the library packs / unpacks it.
+Transport:
+  * ``"rccl"`` (default when the process group's backend is nccl): the library itself calls
+    RCCL over xGMI -- this module only carries the 128-byte unique id from rank 0 to the others;
+  * ``"callbacks"`` (default otherwise, e.g. gloo): host-buffer exchange through
+    ``torch.distributed`` point-to-point calls -- rehearsals where several ranks share one GPU.
 The reference has no counterpart (single process).
 """
 from __future__ import annotations
@@ -22,67 +26,119 @@ from .gp import GP
 
 
 class ShardedGP(GP):
-    def __init__(self, *args, group=None, **kw):
+    def __init__(self, *args, group=None, grid=None, transport=None, rank=None, world=None,
+                 exchange=None, allreduce=None, **kw):
+        """``exchange(rank, ops)`` / ``allreduce(rank, array)`` replace the torch.distributed
+        calls of the callback transport (ops: list of (peer, is_send, memoryview)); with them
+        ``rank`` / ``world`` give this object's place -- several ranks can then live in ONE
+        process (one thread each), which is how the tests rehearse 2x4 and 4x4 grids on one GPU."""
         import torch
         import torch.distributed as dist
         super().__init__(*args, **kw)
-        if not (dist.is_available() and dist.is_initialized()):
-            raise RuntimeError("ShardedGP needs an initialised torch.distributed process group")
         self._torch, self._dist, self._group = torch, dist, group
-        self._rank = dist.get_rank(group)
-        self._world = dist.get_world_size(group)
-        self._backend = dist.get_backend(group)
-        self._staging = None
-        self._staging_n = -1
-
-        def bcast(user, dev_buf, nbytes, root):
-            try:
-                st = self._staging
-                assert dev_buf == st.data_ptr() and nbytes <= st.numel() * 8
-                view = st[: (nbytes + 7) // 8]
-                # group-relative root -> global rank
-                src = dist.get_global_rank(group, root) if group is not None else root
-                dist.broadcast(view, src=src, group=group)
-                # Wait for the collective only: the library's own streams (non-blocking, so
-                # the null stream does not join them) keep running this rank's bulk update
-                # meanwhile; a device-wide synchronize here would serialise the two.
-                torch.cuda.current_stream().synchronize()
-                return 0
-            except Exception as e:  # never let an exception cross the C boundary
-                self._cb_error = e
-                return 1
-
-        def allreduce(user, host_buf, count):
-            try:
-                arr = np.ctypeslib.as_array(host_buf, shape=(count,))
-                dev = "cuda" if self._backend == "nccl" else "cpu"
-                t = torch.from_numpy(arr.copy()).to(dev)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                arr[:] = t.cpu().numpy()
-                return 0
-            except Exception as e:
-                self._cb_error = e
-                return 1
-
+        self._user_exchange, self._user_allreduce = exchange, allreduce
+        have_pg = dist.is_available() and dist.is_initialized() and exchange is None
+        self._rank = dist.get_rank(group) if have_pg else (rank or 0)
+        self._world = dist.get_world_size(group) if have_pg else (world or 1)
+        self._backend = dist.get_backend(group) if have_pg else ("in-process" if exchange else "none")
+        L = _lib.lib()
+        if grid is None:
+            pr, pc = ctypes.c_int(0), ctypes.c_int(0)
+            self._check(L.gogp_dist_grid(self._world, ctypes.byref(pr), ctypes.byref(pc)))
+            grid = (pr.value, pc.value)
+        self.grid = (int(grid[0]), int(grid[1]))
+        if transport is None:
+            transport = "rccl" if self._backend == "nccl" else "callbacks"
+        self.transport = transport
         self._cb_error = None
-        self._bcast_cb = _lib.BCAST_FN(bcast)          # keep the thunks alive
-        self._allreduce_cb = _lib.ALLREDUCE_FN(allreduce)
+        if transport == "rccl":
+            uid = torch.zeros(_lib.GOGP_UNIQUE_ID_BYTES, dtype=torch.uint8)
+            if self._rank == 0:
+                buf = (ctypes.c_char * _lib.GOGP_UNIQUE_ID_BYTES)()
+                self._check(L.gogp_dist_unique_id(buf))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if self._world > 1:
+                dev = "cuda" if self._backend == "nccl" else "cpu"
+                t = uid.to(dev)
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast(t, src=src, group=group)
+                uid = t.cpu()
+            raw = bytes(uid.numpy().tobytes())
+            self._check(L.gogp_dist_init_rccl(self._h, self._rank, self._world, self.grid[0],
+                                              self.grid[1], raw))
+        elif transport == "callbacks":
+            if self._world > 1 and self._backend == "nccl":
+                raise ValueError("the callback transport exchanges host buffers: use a gloo group")
+            self._exchange_cb = _lib.EXCHANGE_FN(self._exchange)   # keep the thunks alive
+            self._allreduce_cb = _lib.ALLREDUCE_FN(self._allreduce)
+            self._check(L.gogp_dist_init_callbacks(
+                self._h, self._rank, self._world, self.grid[0], self.grid[1],
+                ctypes.cast(self._exchange_cb, ctypes.c_void_p),
+                ctypes.cast(self._allreduce_cb, ctypes.c_void_p), None))
+        else:
+            raise ValueError("transport must be 'rccl' or 'callbacks'")
 
-    def _push_data(self):
-        super()._push_data()
-        n = len(self._Y)
-        if n != self._staging_n:
-            L = _lib.lib()
-            nbytes = int(L.gogp_dist_staging_bytes(n))
-            self._staging = self._torch.empty(nbytes // 8, dtype=self._torch.float64, device="cuda")
-            self._check(L.gogp_dist_setup(
-                self._h, self._rank, self._world,
-                ctypes.cast(self._bcast_cb, ctypes.c_void_p), ctypes.cast(self._allreduce_cb, ctypes.c_void_p),
-                None, ctypes.c_void_p(self._staging.data_ptr()), nbytes))
-            self._staging_n = n
+    # ---- callbacks (host buffers; never let an exception cross the C boundary) ----------------
+    def _global(self, r):
+        return self._dist.get_global_rank(self._group, r) if self._group is not None else r
+
+    def _exchange(self, user, ops, nops):
+        try:
+            torch, dist = self._torch, self._dist
+            if self._user_exchange is not None:
+                lst = []
+                for i in range(nops):
+                    o = ops[i]
+                    lst.append((int(o.peer), bool(o.is_send),
+                                memoryview((ctypes.c_char * o.bytes).from_address(o.buf)).cast("B")))
+                self._user_exchange(self._rank, lst)
+                return 0
+            reqs = []
+            keep = []
+            for i in range(nops):
+                o = ops[i]
+                buf = (ctypes.c_char * o.bytes).from_address(o.buf)
+                t = torch.frombuffer(buf, dtype=torch.uint8)
+                keep.append((buf, t))
+                if o.is_send:
+                    reqs.append(dist.isend(t, dst=self._global(o.peer), group=self._group))
+                else:
+                    reqs.append(dist.irecv(t, src=self._global(o.peer), group=self._group))
+            for r in reqs:
+                r.wait()
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self._cb_error = e
+            return 1
+
+    def _allreduce(self, user, host_buf, count):
+        try:
+            if self._user_allreduce is not None:
+                self._user_allreduce(self._rank, np.ctypeslib.as_array(host_buf, shape=(count,)))
+            elif self._world > 1:
+                arr = np.ctypeslib.as_array(host_buf, shape=(count,))
+                t = self._torch.from_numpy(arr)
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self._cb_error = e
+            return 1
 
     def _check(self, rc):
         if rc != _lib.GOGP_OK and self._cb_error is not None:
             e, self._cb_error = self._cb_error, None
             raise RuntimeError("communication callback failed") from e
         super()._check(rc)
+
+    # ---- descriptions for reports -------------------------------------------------------------
+    def grid_text(self) -> str:
+        return "%dx%d" % self.grid
+
+    def transport_text(self) -> str:
+        return ("RCCL inside libgogp_hip (grouped ncclSend/ncclRecv + ncclAllReduce)"
+                if self.transport == "rccl" else
+                "host callbacks over torch.distributed (%s)" % self._backend)
+
+    def local_bytes(self) -> int:
+        """Device bytes of this rank's shard (its tiles of K / L / Y, panel buffers)."""
+        return int(_lib.lib().gogp_dist_local_bytes(self._h))

@@ -189,28 +189,60 @@ int gogp_set_factor(gogp_handle *h, const double *theta_simil,
                     const double *theta_noise, const double *L /* n*n */,
                     const double *alpha /* n */);
 
-/* ---- one evaluation sharded over several GPUs ----------------------------------
- * One process per GPU; every rank holds the full X, y and calls the SAME sequence of
- * gogp_observe / gogp_gradient collectively.  The blocked factorisation is sharded
- * 1-D block-cyclically by 512-wide super-panels of columns: the owner of a
- * super-panel factors it and broadcasts the packed panel; every rank applies the
- * trailing update only to the block columns it owns; the triangular inverse is
- * sharded the same way, K^-1 = Y Y^T and the gradient reduction by tile rows, with
- * one all-reduce of the partial gradient sums.  The reference has no counterpart
- * (single process, goroutines only: gp/gp.go:165-213).
+/* ---- one evaluation sharded over several GPUs: 2-D block-cyclic ---------------------
+ * One process per GPU.  The ranks form a Pr x Pc process grid (rank = pr*Pc + pc; Pr must
+ * divide Pc: 1x1, 1x2, 2x2, 2x4 for 1/2/4/8 GPUs, gogp_dist_grid).  The Gram matrix is cut into
+ * 512x512 tiles; tile (I,J) lives on the GPU at grid position (I mod Pr, J mod Pc), and every
+ * rank allocates ONLY its own tiles (of K, of the factor L and of Y = L^-T): memory per rank
+ * is 1/(Pr*Pc) of the single-GPU footprint (gogp_dist_local_bytes).  X, y (a few MB) are
+ * replicated, so every rank builds its own tiles of K with no communication.  Per block
+ * column P of the blocked right-looking Cholesky: the owner of the diagonal tile factors and
+ * inverts it and sends the inverse out; the process column that owns block column P solves
+ * its tiles of the panel; the panel is then sent along the process rows (each rank gets the
+ * tiles of its own tile rows) and, transposed, along the process columns (the tiles of its
+ * own tile columns); every rank updates its trailing tiles on MFMA.  The triangular inverse
+ * Y = L^-T and K^-1 = Y Y^T run right behind on the same layout with the same exchange, the
+ * gradient reduction runs on the local tiles of K^-1, and the partial sums meet in one
+ * all-reduce.  All ranks call the SAME sequence of gogp_set_data / gogp_absorb / gogp_observe
+ * / gogp_gradient / gogp_produce collectively and get the same LML, gradient, alpha, mu, sigma.
+ * The reference has no counterpart (single process, goroutines only: gp/gp.go:165-213).
  *
- * Communication goes through two callbacks supplied by the host layer (RCCL via
- * torch.distributed on a real node, gloo for rehearsals):
- *   bcast(user, dev_buf, bytes, root): broadcast `bytes` of the staging buffer
- *     (device memory) from rank `root`; must return after the data have arrived;
- *   allreduce(user, host_buf, count): sum `count` host doubles over the ranks in place.
- * `staging` is a device buffer the host layer owns (>= gogp_dist_staging_bytes). */
-typedef int (*gogp_bcast_fn)(void *user, void *dev_buf, int64_t bytes, int root);
+ * Transport, chosen at initialisation (call right after gogp_create, before gogp_set_data):
+ *   gogp_dist_init_rccl       RCCL over xGMI from inside the library: grouped ncclSend /
+ *                             ncclRecv between peers and ncclAllReduce, enqueued on a
+ *                             communication stream and ordered against the compute streams
+ *                             by events (no host synchronisation per panel).  The host layer
+ *                             only has to hand every rank the same 128-byte unique id
+ *                             (made on one rank by gogp_dist_unique_id).
+ *   gogp_dist_init_callbacks  host-synchronous exchange through two callbacks over HOST
+ *                             buffers (the library stages payloads through pinned memory):
+ *                               exchange(user, ops, nops): perform all transfers of the list
+ *                                 (is_send: send `bytes` from buf to rank `peer`; else receive
+ *                                 into buf); returns after all have completed.  Every pair of
+ *                                 ranks lists its mutual transfers in the same order.
+ *                               allreduce(user, host_buf, count): sum doubles over the ranks.
+ *                             For rehearsals where RCCL cannot run (several ranks sharing one
+ *                             GPU, gloo) and for hosts with their own transport (MPI, sockets). */
+#define GOGP_UNIQUE_ID_BYTES 128
+typedef struct gogp_xfer {
+  int32_t peer;    /* rank of the other side                                       */
+  int32_t is_send; /* 1: send from buf, 0: receive into buf                        */
+  void *buf;       /* host memory, valid until the callback returns                */
+  int64_t bytes;
+} gogp_xfer;
+typedef int (*gogp_exchange_fn)(void *user, const gogp_xfer *ops, int32_t nops);
 typedef int (*gogp_allreduce_fn)(void *user, double *host_buf, int64_t count);
-int64_t gogp_dist_staging_bytes(int64_t n);
-int gogp_dist_setup(gogp_handle *h, int rank, int nranks, gogp_bcast_fn bcast,
-                    gogp_allreduce_fn allreduce, void *user, void *staging,
-                    int64_t staging_bytes);
+/* Default process grid for `nranks` GPUs: 1x1, 1x2, 2x2, 2x4, (16: 4x4). */
+int gogp_dist_grid(int nranks, int *prow, int *pcol);
+int gogp_dist_unique_id(void *id128 /* GOGP_UNIQUE_ID_BYTES */);
+int gogp_dist_init_rccl(gogp_handle *h, int rank, int nranks, int prow, int pcol,
+                        const void *id128);
+int gogp_dist_init_callbacks(gogp_handle *h, int rank, int nranks, int prow, int pcol,
+                             gogp_exchange_fn exchange, gogp_allreduce_fn allreduce,
+                             void *user);
+/* Device bytes this rank holds for the N-dependent state (its tiles of K / L / Y, panel
+ * buffers, block inverses); 0 before gogp_set_data or on an unsharded handle. */
+int64_t gogp_dist_local_bytes(const gogp_handle *h);
 
 /* ---- measurement hooks (bench.py / tests; not part of the reference API) --- */
 
