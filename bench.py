@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-produce", action="store_true",
                     help="skip the secondary Produce measurement (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--candidates", type=int, default=4,
+                    help="N <= 8192: also time this many candidates evaluated concurrently")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300)
     args = ap.parse_args()
@@ -163,6 +165,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries exactly ONE line (the JSON): whatever libraries print there (gloo's
+    # connection notes, RCCL's version banner) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
 
     import torch
     if not torch.cuda.is_available():
@@ -203,7 +211,7 @@ def main():
             if rank == 0:
                 line = out_holder["line"] or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
                 line["error"] = "collective timed out after %d s" % args.sharded_timeout
-                print(json.dumps(line), flush=True)
+                print(json.dumps(line), file=json_out, flush=True)
             os._exit(3)
 
         wd = threading.Timer(args.sharded_timeout, _bail)
@@ -345,6 +353,30 @@ def main():
                 "note": "8 B per lower-triangle element written (Gram; the part built on the main "
                         "stream) / read (K^-1 in the fused gradient reduction); HIP events on the "
                         "kernel's stream"}
+        if world == 1 and N <= 8192 and args.candidates > 1:
+            # below N ~ 8192 one evaluation is a chain of small dependent launches: k candidates
+            # evaluated at once (gogp_observe_gradient_batch; the reference's optimiser can do the
+            # same, optimize.Settings.Concurrent, tutorial/tutorial.go:141) overlap their chains
+            k = args.candidates
+            gps = [g] + [G.GP(D, simil, noise, device=local_rank) for _ in range(k - 1)]
+            for gg in gps[1:]:
+                gg.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
+            xs = np.array([wl.log_theta(i) for i in range(k)])
+            G.observe_gradient_batch(gps, xs)
+            torch.cuda.synchronize()
+            reps = max(5, steps // k)
+            tb = time.perf_counter()
+            for r in range(reps):
+                xs = np.array([wl.log_theta(r * k + i) for i in range(k)])
+                G.observe_gradient_batch(gps, xs)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            out["concurrent_candidates"] = {
+                "k": k, "evals_per_s": reps * k / tb, "ms_per_batch": tb / reps * 1e3,
+                "note": "k independent candidates evaluated at once on this GPU, one handle and one "
+                        "host thread each; `value` above is ONE candidate at a time"}
+            for gg in gps[1:]:
+                gg.close()
         if world == 1 and not args.no_produce and g is not None:
             # secondary metric: Produce throughput at the same N, M = 1024 fresh
             # test points per call, host Z in / host mu, sigma out -- outside the timed region
@@ -441,7 +473,7 @@ def main():
             out["grad_rel_err_vs_oracle"] = errs["grad_rel_err_vs_oracle"]
             out["mu_rel_err_vs_oracle"] = errs["mu_rel_err_vs_oracle"]
             out["sigma_rel_err_vs_oracle"] = errs["sigma_rel_err_vs_oracle"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -49,6 +49,8 @@ SYMBOLS = [
     ("gogp_observe_full", ctypes.c_int, [_h, _dp, _i64, _dp]),
     ("gogp_lml", ctypes.c_int, [_h, _dp]),
     ("gogp_gradient", ctypes.c_int, [_h, _dp, _i64]),
+    ("gogp_observe_gradient_batch", ctypes.c_int,
+     [ctypes.POINTER(_h), ctypes.c_int, _dp, _i64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     ("gogp_produce", ctypes.c_int, [_h, _dp, _i64, _dp, _dp]),
     ("gogp_n", _i64, [_h]),
     ("gogp_get_alpha", ctypes.c_int, [_h, _dp]),

@@ -274,6 +274,35 @@ class GP:
         return ms.value, nl.value
 
 
+def observe_gradient_batch(gps: Sequence[GP], xs) -> tuple:
+    """Observe(xs[i]) + Gradient() on gps[i] for all i at once (hyperparameters-only form;
+    every GP holds its own copy of the data): the k evaluations overlap on the GPU.
+    Counterpart: candidates evaluated concurrently by the reference's optimiser
+    (optimize.Settings.Concurrent = NTASKS, tutorial/tutorial.go:30,141).
+    Returns (lmls[k], grads[k x P])."""
+    k = len(gps)
+    xs = _arr(xs).reshape(k, -1)
+    P = xs.shape[1]
+    for g in gps:
+        if P != g._ns + g._nn:
+            raise ValueError("len(x)")
+        g._push_data()
+        g._with_obs = False
+    hs = (ctypes.c_void_p * k)(*[g._h for g in gps])
+    lmls, grads = np.zeros(k), np.zeros((k, P))
+    st = (ctypes.c_int * k)()
+    rc = _lib.lib().gogp_observe_gradient_batch(hs, k, _dp(xs), P, _dp(lmls), _dp(grads), st)
+    for i, g in enumerate(gps):
+        if st[i] != _lib.GOGP_OK:
+            g._check(st[i])
+        theta = np.exp(xs[i])
+        g.ThetaSimil, g.ThetaNoise = list(theta[:g._ns]), list(theta[g._ns:])
+        g._last_len = P
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "observe_gradient_batch")
+    return lmls, grads
+
+
 class Model:
     """gp.Model (gp/model.go:9-28): GP plus priors on the hyperparameters.
     ``Priors`` is any object with Observe(x) -> float and Gradient() -> array."""

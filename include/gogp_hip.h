@@ -162,6 +162,16 @@ int gogp_lml(gogp_handle *h, double *lml);
  * (gp/gp.go:427-430). */
 int gogp_gradient(gogp_handle *h, double *grad, int64_t len);
 
+/* k independent Observe + Gradient evaluations at once: handle hs[i] (each created and given
+ * its data separately; they may hold the same data) evaluates x[i*len .. (i+1)*len) from its own
+ * host thread, so the dependent launch chains of the k evaluations overlap on the GPU.
+ * Counterpart: the reference's optimiser evaluating candidates concurrently
+ * (optimize.Settings.Concurrent = NTASKS, tutorial/tutorial.go:30,141).  status (may be NULL)
+ * receives the k return codes; the result is the first non-zero one. */
+int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double *x, int64_t len,
+                                double *lmls /* k */, double *grads /* k*len */,
+                                int *status /* k */);
+
 /* gp.GP.Produce (gp/gp.go:258-360): predictive mean and standard deviation of
  * the latent function at m points Z (row-major m x ndim).  sigma_j =
  * sqrt(k(z_j,z_j) - (Kstar^T K^-1 Kstar)_jj), unclamped like the reference

@@ -512,6 +512,26 @@ def test_schedule_options_same_results(gpmod, opts, n):
     ref.close()
 
 
+def test_observe_gradient_batch_matches_single_calls(gpmod):
+    """k candidates evaluated at once (one host thread per handle) give bit for bit what the
+    same handles return one at a time."""
+    rng = np.random.default_rng(53)
+    n, D, k = 1200, 3, 4
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.Matern32), kernel.UniformNoise
+    xs = np.log(np.array([[1.0, 0.5, 0.2], [1.2, 0.6, 0.25], [0.8, 0.4, 0.15], [1.1, 0.7, 0.3]]))
+    gps = [gpmod.GP(D, simil, noise, X=X, Y=y) for _ in range(k)]
+    want = [(g.Observe(x), g.Gradient()) for g, x in zip(gps, xs)]
+    for _ in range(3):
+        lmls, grads = gpmod.observe_gradient_batch(gps, xs)
+        for i in range(k):
+            assert lmls[i] == want[i][0]
+            np.testing.assert_array_equal(grads[i], want[i][1])
+    np.testing.assert_array_equal(gps[2].Gradient(), want[2][1])  # the handles stay usable
+    for g in gps:
+        g.close()
+
+
 def test_later_handles_as_fast_as_the_first(gpmod):
     """Stream sets are pooled (api.hip): a GP created after others were closed must run as
     fast as the first one.  With hipStreamDestroy + fresh streams every later handle of the
