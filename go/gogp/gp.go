@@ -58,14 +58,25 @@ type GP struct {
 
 	Parallel bool // accepted for compatibility; the device path is always parallel
 
-	L     []float64 // lower Cholesky factor, row-major n x n (gonum keeps U = L^T)
+	// Cached computations (gp/gp.go:34-36).  Alpha is refreshed by every Absorb / Observe;
+	// the factor is fetched on demand by Factor() (n*n doubles over PCIe are not free).
 	Alpha []float64 // K^-1 y
 
 	h       *C.gogp_handle
 	withObs bool
 	lastLen int
-	dirty   bool
+	// X, Y are uploaded only when they changed.  Absorb and the full form of Observe assign
+	// them; code that writes gp.X / gp.Y directly (the reference's tutorial does:
+	// tutorial/tutorial.go:114-115) is detected by comparing the slice headers below, and
+	// in-place edits of the same backing arrays must call Touch().
+	dirty      bool
+	upX        *[]float64 // &gp.X[0] at the time of the last upload
+	upY        *float64   // &gp.Y[0] at the time of the last upload
+	upN        int
 }
+
+// Touch marks X / Y as modified in place: the next Absorb / Observe uploads them again.
+func (gp *GP) Touch() { gp.dirty = true }
 
 func (gp *GP) handle() *C.gogp_handle {
 	if gp.h != nil {
@@ -91,7 +102,11 @@ func (gp *GP) handle() *C.gogp_handle {
 	if gp.Noise == nil { // gp/gp.go:45-48: ConstantNoise(1e-5)
 		d.noise_kind, d.noise_std = C.GOGP_NOISE_CONSTANT, 1e-5
 	} else {
-		kind, std, scale := gp.Noise.(DeviceNoise).NoiseDesc()
+		dn, ok := gp.Noise.(DeviceNoise)
+		if !ok {
+			panic("gogp: Noise does not implement DeviceNoise; use the reference package for arbitrary Go kernels")
+		}
+		kind, std, scale := dn.NoiseDesc()
 		d.noise_kind, d.noise_std, d.noise_scale = C.int32_t(kind), C.double(std), C.double(scale)
 	}
 	if rc := C.gogp_create(&d, -1, &gp.h); rc != C.GOGP_OK {
@@ -116,14 +131,41 @@ func dptr(s []float64) *C.double {
 	return (*C.double)(unsafe.Pointer(&s[0]))
 }
 
-// pushData packs X ([][]float64, not contiguous) row-major and copies X, Y to the device.
+// changed reports whether gp.X / gp.Y were re-assigned since the last upload.
+func (gp *GP) changed() bool {
+	if gp.dirty || len(gp.X) != gp.upN || len(gp.Y) != gp.upN {
+		return true
+	}
+	if gp.upN == 0 {
+		return false
+	}
+	return &gp.X[0] != gp.upX || &gp.Y[0] != gp.upY
+}
+
+// pushData packs X ([][]float64, not contiguous) row-major and copies X, Y to the device --
+// only when they changed: a hyperparameter step must not pay an O(N*D) host-to-device copy
+// and a drain of the device streams.
 func (gp *GP) pushData() error {
+	h := gp.handle()
+	if !gp.changed() {
+		return nil
+	}
 	n := len(gp.X)
+	if len(gp.Y) != n {
+		return fmt.Errorf("gogp: len(X) != len(Y)")
+	}
 	flat := make([]float64, n*gp.NDim)
 	for i, row := range gp.X {
 		copy(flat[i*gp.NDim:], row)
 	}
-	return gp.err(C.gogp_set_data(gp.handle(), dptr(flat), dptr(gp.Y), C.int64_t(n)))
+	if err := gp.err(C.gogp_set_data(h, dptr(flat), dptr(gp.Y), C.int64_t(n))); err != nil {
+		return err
+	}
+	gp.dirty, gp.upN = false, n
+	if n > 0 {
+		gp.upX, gp.upY = &gp.X[0], &gp.Y[0]
+	}
+	return nil
 }
 
 func (gp *GP) defaults() { // gp/gp.go:45-57
@@ -150,10 +192,25 @@ func (gp *GP) Absorb(x [][]float64, y []float64) (err error) {
 	if len(tn) == 0 {
 		tn = []float64{0}
 	}
-	if err = gp.err(C.gogp_absorb(gp.handle(), dptr(gp.ThetaSimil), dptr(tn))); err != nil {
-		return err // gp/gp.go:228-230
+	rc := C.gogp_absorb(gp.handle(), dptr(gp.ThetaSimil), dptr(tn))
+	if rc != C.GOGP_OK && rc != C.GOGP_ECOND {
+		return gp.err(rc) // gp/gp.go:228-230
 	}
-	return gp.fetchState()
+	if err = gp.fetchState(); err != nil {
+		return err
+	}
+	return gp.err(rc) // GOGP_ECOND: gonum's Condition error, returned as gp/gp.go:233-236 does
+}
+
+// Factor returns the lower Cholesky factor, row-major n x n (gonum's mat.Cholesky keeps
+// U = L^T: gp.GP.L of the reference, gp/gp.go:35).
+func (gp *GP) Factor() ([]float64, error) {
+	n := int(C.gogp_n(gp.handle()))
+	L := make([]float64, n*n)
+	if err := gp.err(C.gogp_get_factor(gp.h, dptr(L))); err != nil {
+		return nil, err
+	}
+	return L, nil
 }
 
 func (gp *GP) fetchState() error {
@@ -213,9 +270,18 @@ func (gp *GP) Observe(x []float64) float64 {
 			gp.X[i] = x[P+i*gp.NDim : P+(i+1)*gp.NDim]
 		}
 		gp.Y = x[P+n*gp.NDim:]
+		// the device holds exactly these data now (gogp_observe_full replaced them), unless the
+		// call failed half-way
+		gp.dirty, gp.upN = rc != C.GOGP_OK, n
+		if n > 0 {
+			gp.upX, gp.upY = &gp.X[0], &gp.Y[0]
+		}
 	}
 	if err := gp.err(rc); err != nil {
-		panic(err) // gp/gp.go:402-405
+		panic(err) // gp/gp.go:402-405 (also gonum's Condition error: GOGP_ECOND)
+	}
+	if err := gp.fetchState(); err != nil { // Alpha is part of the documented state (gp/gp.go:255-257)
+		panic(err)
 	}
 	for i := range gp.ThetaSimil { // gp/gp.go:384-385
 		gp.ThetaSimil[i] = math.Exp(x[i])

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgogp_hip.so")
 HOOKS_PATH = os.path.join(_HERE, "libgogp_testhooks.so")
 
-GOGP_OK, GOGP_EARG, GOGP_ENOTPD, GOGP_EHIP, GOGP_ESTATE, GOGP_ENOMEM = 0, 1, 2, 3, 4, 5
+GOGP_OK, GOGP_EARG, GOGP_ENOTPD, GOGP_EHIP, GOGP_ESTATE, GOGP_ENOMEM, GOGP_ECOND = 0, 1, 2, 3, 4, 5, 6
 
 #: every symbol include/gogp_hip.h declares: (name, restype, argtypes)
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -37,7 +37,7 @@ static thread_local std::string g_create_error;
 
 // ---- descriptor helpers -------------------------------------------------------
 extern "C" int gogp_desc_ntheta_noise(const gogp_desc *d) {
-  return (d && d->noise_kind == GOGP_NOISE_UNIFORM) ? 1 : 0;
+  return (d && (d->noise_kind == GOGP_NOISE_UNIFORM || d->noise_kind == GOGP_NOISE_CONSTANT_PARAM)) ? 1 : 0;
 }
 
 extern "C" int gogp_desc_check(const gogp_desc *d) {
@@ -45,7 +45,8 @@ extern "C" int gogp_desc_check(const gogp_desc *d) {
   if (d->ndim < 1 || d->ndim > GOGP_MAX_NDIM) return GOGP_EARG;
   if (d->nterms < 1 || d->nterms > GOGP_MAX_TERMS) return GOGP_EARG;
   if (d->ntheta_simil < 1 || d->ntheta_simil > GOGP_MAX_NDIM + 8) return GOGP_EARG;
-  if (d->noise_kind != GOGP_NOISE_CONSTANT && d->noise_kind != GOGP_NOISE_UNIFORM)
+  if (d->noise_kind != GOGP_NOISE_CONSTANT && d->noise_kind != GOGP_NOISE_UNIFORM &&
+      d->noise_kind != GOGP_NOISE_CONSTANT_PARAM)
     return GOGP_EARG;
   int nard = 0;
   for (int t = 0; t < d->nterms; ++t) {
@@ -328,8 +329,9 @@ int gogp_upload_params(gogp_handle *h) {
     for (int j = 0; j < d.ndim; ++j)
       p.inv_len[t][j] = 1.0 / h->theta_s[T.len_idx + (T.ard ? j : 0)];
   }
-  if (d.noise_kind == GOGP_NOISE_CONSTANT) {
-    p.noise_var = d.noise_std * d.noise_std;  // kernel/noise.go:27-30
+  if (d.noise_kind == GOGP_NOISE_CONSTANT || d.noise_kind == GOGP_NOISE_CONSTANT_PARAM) {
+    // kernel/noise.go:27-30; tutorial/anynoise/kernel/kernel.go:31-33 (the parameter is unused)
+    p.noise_var = d.noise_std * d.noise_std;
     p.dnoise = 0.0;
   } else {
     const double sd = h->theta_n[0];
@@ -538,7 +540,7 @@ static int factorize(gogp_handle *h, bool eager) {
   }
   order(h, EV_FWD, sz, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
   if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
@@ -579,6 +581,19 @@ static int factorize(gogp_handle *h, bool eager) {
   h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
   h->factored = true;
   h->have_alpha = true;
+  // gonum's Cholesky solves return a Condition error when its condition estimate exceeds
+  // 1e16 (mat.ConditionTolerance), which gp/gp.go:233-236 passes on (Absorb: error, Observe:
+  // panic).  (max L_ii / min L_ii)^2 is a lower bound of cond_2(K); beyond 1e16 the matrix is
+  // numerically singular whatever the estimator.  The factor, alpha and LML stay available.
+  const double dmin = h->hscal[3], dmax = h->hscal[4];
+  h->cond_lb = (dmin > 0.0) ? (dmax / dmin) * (dmax / dmin) : INFINITY;
+  if (!(h->cond_lb <= h->cond_limit)) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "Condition: matrix singular or near-singular with condition number >= %.4e",
+             h->cond_lb);
+    h->err = buf;
+    return GOGP_ECOND;
+  }
   return GOGP_OK;
 }
 
@@ -622,11 +637,12 @@ extern "C" int gogp_absorb(gogp_handle *h, const double *theta_simil,
     return GOGP_OK;
   }
   rc = h->dist ? gogp_dist_factorize(h, false) : factorize(h, false);
-  if (rc != GOGP_OK) return rc;
+  if (rc != GOGP_OK && rc != GOGP_ECOND) return rc;
+  const int rcond = rc;
   rc = ensure_alpha(h);  // gp/gp.go:232-236
   if (rc != GOGP_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->s));
-  return GOGP_OK;
+  return rcond;
 }
 
 static int observe_theta(gogp_handle *h, const double *x, double *lml) {
@@ -645,10 +661,10 @@ static int observe_theta(gogp_handle *h, const double *x, double *lml) {
   }
   rc = h->dist ? gogp_dist_factorize(h, true)
                : factorize(h, h->eager != 0);  // gp/gp.go:402 (with gradient preparation)
-  if (rc != GOGP_OK) return rc;
+  if (rc != GOGP_OK && rc != GOGP_ECOND) return rc;
   h->observed = true;
   if (lml) *lml = h->lml;  // gp/gp.go:412
-  return GOGP_OK;
+  return rc;
 }
 
 extern "C" int gogp_observe(gogp_handle *h, const double *x, int64_t len, double *lml) {
@@ -1074,6 +1090,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   }
   if (strcmp(name, "eager") == 0) {
     h->eager = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "cond_limit_log10") == 0) {  // gonum: mat.ConditionTolerance (a package variable), 1e16
+    if (value < 1 || value > 300) return fail(h, GOGP_EARG, "cond_limit_log10 must be 1..300");
+    h->cond_limit = pow(10.0, (double)value);
     return GOGP_OK;
   }
   if (strcmp(name, "superpanel") == 0) {

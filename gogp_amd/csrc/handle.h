@@ -57,6 +57,8 @@ struct gogp_handle {
   bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
   bool observed = false, with_obs = false;
   double lml = 0.0;
+  double cond_lb = 1.0;  // (max L_ii / min L_ii)^2 of the last factorisation
+  double cond_limit = 1e16;  // gonum's mat.ConditionTolerance
   std::vector<double> grad_cache;
   bool grad_valid = false;
   int64_t notpd = -1;

@@ -157,16 +157,19 @@ void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const doubl
 }
 
 // scalars[0] = sum_{i<n} 2 log L_ii ; scalars[1] = sum_{i<n} z_i^2 ;
-// scalars[2] = sum_{i<n} y_i alpha_i (only if alpha != nullptr)
+// scalars[2] = sum_{i<n} y_i alpha_i (only if alpha != nullptr); scalars[3], [4] = min, max L_ii
 __global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restrict__ L, long ld,
                                                            const double *__restrict__ z,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ alpha,
                                                            long n, double *__restrict__ scalars) {
-  __shared__ double red[3][16];
-  double a = 0.0, b = 0.0, c = 0.0;
+  __shared__ double red[5][16];
+  double a = 0.0, b = 0.0, c = 0.0, dmin = INFINITY, dmax = 0.0;
   for (long i = threadIdx.x; i < n; i += 1024) {
-    a += 2.0 * log(L[i * ld + i]);
+    const double lii = L[i * ld + i];
+    a += 2.0 * log(lii);
+    dmin = fmin(dmin, lii);
+    dmax = fmax(dmax, lii);
     const double zi = z[i];
     b += zi * zi;
     if (alpha) c += y[i] * alpha[i];
@@ -174,23 +177,34 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restr
   a = wave_sum(a);
   b = wave_sum(b);
   c = wave_sum(c);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dmin = fmin(dmin, __shfl_xor(dmin, o));
+    dmax = fmax(dmax, __shfl_xor(dmax, o));
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wid] = a;
     red[1][wid] = b;
     red[2][wid] = c;
+    red[3][wid] = dmin;
+    red[4][wid] = dmax;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double sa = 0, sb = 0, sc = 0;
+    double sa = 0, sb = 0, sc = 0, mn = INFINITY, mx = 0.0;
     for (int w = 0; w < 16; ++w) {
       sa += red[0][w];
       sb += red[1][w];
       sc += red[2][w];
+      mn = fmin(mn, red[3][w]);
+      mx = fmax(mx, red[4][w]);
     }
     scalars[0] = sa;
     scalars[1] = sb;
     scalars[2] = sc;
+    scalars[3] = mn;  // min / max L_ii: (max/min)^2 bounds cond_2(K) from below
+    scalars[4] = mx;
   }
 }
 

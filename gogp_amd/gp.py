@@ -38,6 +38,15 @@ class FactorizeError(GogpError):
         self.pivot = pivot
 
 
+class ConditionError(GogpError):
+    """gonum's mat.Condition error (cond > 1e16) that gp/gp.go:233-236 returns from Absorb
+    and turns into a panic in Observe: K factored, but it is numerically singular.  The state
+    (L, Alpha, LML) was stored before the error was reported, as in gonum."""
+
+    def __init__(self, msg: str):
+        super().__init__(_lib.GOGP_ECOND, msg)
+
+
 def _dp(a: Optional[np.ndarray]):
     if a is None:
         return None
@@ -62,7 +71,7 @@ class GP:
         # build_desc); zero theta vectors when empty
         self._desc = build_desc(self.NDim, Simil, Noise)
         self._ns = Simil.NTheta()
-        self._nn = 1 if self._desc.noise_kind == 1 else 0
+        self._nn = 0 if self._desc.noise_kind == 0 else 1
         self.ThetaSimil: List[float] = list(ThetaSimil) if ThetaSimil is not None else [0.0] * self._ns
         self.ThetaNoise: List[float] = list(ThetaNoise) if ThetaNoise is not None else [0.0] * self._nn
         #: accepted for source compatibility; the device path is always parallel
@@ -102,6 +111,8 @@ class GP:
         msg = L.gogp_last_error(self._h).decode()
         if rc == _lib.GOGP_ENOTPD:
             raise FactorizeError(msg, int(L.gogp_notpd_index(self._h)))
+        if rc == _lib.GOGP_ECOND:
+            raise ConditionError(msg)
         raise GogpError(rc, msg)
 
     # ---- data: gp.GP.X / gp.GP.Y (gp/gp.go:27-28) --------------------------------

@@ -7,6 +7,11 @@
 // argument meaning and error behaviour follow the reference: Absorb returns an
 // error code (gp/gp.go:228-230), Observe throws where the reference panics
 // (gp/gp.go:398-405), Produce returns false on error (gp/gp.go:338-340).
+//
+// X / Y are uploaded only when they changed: assign them through SetData() (or Absorb);
+// after writing into the public X / Y members directly call Touch().  Alpha is refreshed
+// after every Absorb / Observe, L lazily by Factor() (the reference documents L, Alpha, X,
+// ThetaSimil, ThetaNoise as the state Produce depends on: gp/gp.go:35-36,255-257).
 #pragma once
 #include <cmath>
 #include <stdexcept>
@@ -32,6 +37,8 @@ class GP {
   std::vector<std::vector<double>> X;
   std::vector<double> Y;
   bool Parallel = false;  // accepted for compatibility
+  // Cached computations (gp/gp.go:34-36)
+  std::vector<double> Alpha;  // K^-1 y, refreshed by Absorb / Observe
 
   explicit GP(const gogp_desc &d, int device = -1) : NDim(d.ndim), desc(d) {
     if (gogp_create(&desc, device, &h_) != GOGP_OK)
@@ -45,13 +52,24 @@ class GP {
 
   // gp/gp.go:80-87
   int Absorb(const std::vector<std::vector<double>> &x, const std::vector<double> &y) {
-    X = x;
-    Y = y;
+    SetData(x, y);
     int rc = push();
     if (rc != GOGP_OK) return rc;
     double zero = 0.0;
-    return gogp_absorb(h_, ThetaSimil.data(), ThetaNoise.empty() ? &zero : ThetaNoise.data());
+    rc = gogp_absorb(h_, ThetaSimil.data(), ThetaNoise.empty() ? &zero : ThetaNoise.data());
+    if (rc != GOGP_OK && rc != GOGP_ECOND) return rc;  // gp/gp.go:228-230
+    const int ra = fetch_alpha();
+    return ra != GOGP_OK ? ra : rc;  // GOGP_ECOND: gonum's Condition error, gp/gp.go:233-236
   }
+
+  // Assign the observations (gp.GP.X / gp.GP.Y); uploaded on the next Absorb / Observe.
+  void SetData(const std::vector<std::vector<double>> &x, const std::vector<double> &y) {
+    X = x;
+    Y = y;
+    dirty_ = true;
+  }
+  // Call after modifying the public X / Y members in place.
+  void Touch() { dirty_ = true; }
 
   // gp/gp.go:244-253
   double LML() {
@@ -75,12 +93,21 @@ class GP {
     if (x.size() < P) throw Error(GOGP_EARG, "len(x)");
     double lml = 0;
     if (x.size() == P) {
-      check(push());
+      check(push());  // uploads only if X / Y changed since the last call
       check(gogp_observe(h_, x.data(), (int64_t)x.size(), &lml));
     } else {
       if ((x.size() - P) % (NDim + 1)) throw Error(GOGP_EARG, "len(x)");  // gp/gp.go:398-400
-      check(gogp_observe_full(h_, x.data(), (int64_t)x.size(), &lml));
+      const int rc = gogp_observe_full(h_, x.data(), (int64_t)x.size(), &lml);
+      // gp/gp.go:391-396: X, Y are re-sliced from x (the device holds them now)
+      const size_t n = (x.size() - P) / (size_t)(NDim + 1);
+      X.assign(n, std::vector<double>((size_t)NDim));
+      for (size_t i = 0; i < n; ++i)
+        for (int d = 0; d < NDim; ++d) X[i][d] = x[P + i * NDim + d];
+      Y.assign(x.begin() + (long)(P + n * NDim), x.end());
+      dirty_ = rc != GOGP_OK;
+      check(rc);
     }
+    check(fetch_alpha());
     for (size_t i = 0; i < ThetaSimil.size(); ++i) ThetaSimil[i] = std::exp(x[i]);
     for (size_t i = 0; i < ThetaNoise.size(); ++i) ThetaNoise[i] = std::exp(x[ThetaSimil.size() + i]);
     last_len_ = x.size();
@@ -94,11 +121,12 @@ class GP {
     return g;
   }
 
-  // gp.GP.Alpha / gp.GP.L (gp/gp.go:35-36)
-  std::vector<double> Alpha() {
-    std::vector<double> a((size_t)gogp_n(h_));
-    check(gogp_get_alpha(h_, a.data()));
-    return a;
+  // gp.GP.L (gp/gp.go:35): lower factor, row-major n x n, fetched on demand
+  std::vector<double> Factor() {
+    const size_t n = (size_t)gogp_n(h_);
+    std::vector<double> L(n * n);
+    check(gogp_get_factor(h_, L.data()));
+    return L;
   }
 
   gogp_handle *handle() { return h_; }
@@ -106,6 +134,7 @@ class GP {
  private:
   gogp_handle *h_ = nullptr;
   size_t last_len_ = 0;
+  bool dirty_ = true;
 
   std::vector<double> pack(const std::vector<std::vector<double>> &x) const {
     std::vector<double> flat(x.size() * (size_t)NDim);
@@ -114,8 +143,16 @@ class GP {
     return flat;
   }
   int push() {
+    if (!dirty_) return GOGP_OK;
+    if (X.size() != Y.size()) return GOGP_EARG;
     std::vector<double> flat = pack(X);
-    return gogp_set_data(h_, flat.data(), Y.data(), (int64_t)Y.size());
+    const int rc = gogp_set_data(h_, flat.data(), Y.data(), (int64_t)Y.size());
+    if (rc == GOGP_OK) dirty_ = false;
+    return rc;
+  }
+  int fetch_alpha() {
+    Alpha.assign((size_t)gogp_n(h_), 0.0);
+    return gogp_get_alpha(h_, Alpha.data());
   }
   void check(int rc) {
     if (rc != GOGP_OK) throw Error(rc, gogp_last_error(h_));

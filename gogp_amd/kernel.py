@@ -31,7 +31,7 @@ GOGP_MAX_TERMS = 4
 GOGP_MAX_NDIM = 64
 
 K_NORMAL, K_MATERN32, K_MATERN52, K_MATERN52_TEXTBOOK, K_PERIODIC = 0, 1, 2, 3, 4
-NOISE_CONSTANT, NOISE_UNIFORM = 0, 1
+NOISE_CONSTANT, NOISE_UNIFORM, NOISE_CONSTANT_PARAM = 0, 1, 2
 
 SQRT3 = 1.7320508075688772  # kernel/kernel.go:51
 SQRT5 = 2.2360679774997900  # kernel/kernel.go:52
@@ -223,22 +223,31 @@ class NoiseKernel:
         self.scale = float(scale)
 
     def NTheta(self) -> int:
-        return 1 if self.kind == NOISE_UNIFORM else 0
+        return 0 if self.kind == NOISE_CONSTANT else 1
 
     def Observe(self, x: Sequence[float]) -> float:
-        if self.kind == NOISE_CONSTANT:  # kernel/noise.go:23-30
+        if self.kind in (NOISE_CONSTANT, NOISE_CONSTANT_PARAM):  # kernel/noise.go:23-30
             return self.std * self.std
         return self.scale * x[0] * x[0]  # kernel/noise.go:43-49
 
     def __repr__(self):
         if self.kind == NOISE_CONSTANT:
             return "ConstantNoise(%g)" % self.std
+        if self.kind == NOISE_CONSTANT_PARAM:
+            return "ConstantNoiseParam(%g)" % self.std
         return "%g*UniformNoise" % self.scale
 
 
 def ConstantNoise(std: float) -> NoiseKernel:
     """kernel.ConstantNoise(std): variance std^2, no parameters (kernel/noise.go:18-34)."""
     return NoiseKernel(NOISE_CONSTANT, std=std)
+
+
+def ConstantNoiseParam(std: float) -> NoiseKernel:
+    """Constant variance std^2 with ONE parameter the Gram matrix does not depend on -- the
+    noise kernel of tutorial/anynoise/kernel/kernel.go:26-35 (``return 1e-5``, ``NTheta() == 1``):
+    the parameter exists only so that the model's priors can use it; its LML gradient is 0."""
+    return NoiseKernel(NOISE_CONSTANT_PARAM, std=std)
 
 
 #: kernel.UniformNoise (kernel/noise.go:36-53): one parameter, the standard error

@@ -50,9 +50,9 @@ def func_grad(m):
 def _is_not_positive_definite(e: Exception) -> bool:
     if isinstance(e, (np.linalg.LinAlgError, ArithmeticError)):
         return True
-    if getattr(e, "code", None) == 2:  # GOGP_ENOTPD (gp.FactorizeError)
+    if getattr(e, "code", None) in (2, 6):  # GOGP_ENOTPD / GOGP_ECOND: K not usable at this point
         return True
-    return type(e).__name__ in ("FactorizeError", "NotPositiveDefinite")
+    return type(e).__name__ in ("FactorizeError", "ConditionError", "NotPositiveDefinite")
 
 
 def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,

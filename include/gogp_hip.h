@@ -33,6 +33,13 @@ extern "C" {
 #define GOGP_EHIP 3   /* HIP runtime error / no device / extension unusable    */
 #define GOGP_ESTATE 4 /* call order (Gradient before Observe, ...)             */
 #define GOGP_ENOMEM 5
+#define GOGP_ECOND 6  /* K factored but numerically singular: gonum's Condition error
+                         (cond > 1e16) from Cholesky.SolveVecTo / SolveTo, passed on by
+                         gp/gp.go:233-236,338-340.  Here: (max L_ii/min L_ii)^2 > 1e16, a
+                         lower bound of cond_2(K).  The factor, alpha and the LML are
+                         still stored (as in gonum, which fills the result and returns the
+                         error); the host shim decides: Absorb returns it as an error,
+                         Observe panics, exactly where the reference does.          */
 
 /* ---- kernel descriptors --------------------------------------------------
  * The reference accepts any Go value implementing
@@ -67,9 +74,14 @@ enum gogp_simil_kind {
 enum gogp_noise_kind {
   GOGP_NOISE_CONSTANT = 0, /* kernel.ConstantNoise(std): var=std^2, NTheta=0
                               kernel/noise.go:21-34                             */
-  GOGP_NOISE_UNIFORM = 1   /* scale*kernel.UniformNoise: var=scale*std^2,
+  GOGP_NOISE_UNIFORM = 1,  /* scale*kernel.UniformNoise: var=scale*std^2,
                               NTheta=1  kernel/noise.go:39-53; scale as in
                               tutorial/barebones/kernel/kernel.go:25-31         */
+  GOGP_NOISE_CONSTANT_PARAM = 2 /* constant variance noise_std^2 WITH one parameter
+                              the Gram matrix does not depend on (NTheta=1, its
+                              gradient component is 0): the noise kernel of
+                              tutorial/anynoise/kernel/kernel.go:26-35, whose
+                              parameter only feeds the priors                   */
 };
 
 typedef struct gogp_term {
@@ -101,7 +113,7 @@ typedef struct gogp_handle gogp_handle;
 /* Validate a descriptor; returns GOGP_OK or GOGP_EARG.  Pure host code. */
 int gogp_desc_check(const gogp_desc *desc);
 
-/* Number of noise parameters, Noise.NTheta(): 0 or 1. */
+/* Number of noise parameters, Noise.NTheta(): 0 (CONSTANT) or 1. */
 int gogp_desc_ntheta_noise(const gogp_desc *desc);
 
 /* Create a handle on HIP device `device` (-1: the current device).
@@ -282,6 +294,8 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "eager"        1 | 0   Observe also runs the triangular inverse (gradient preparation)
  *                          behind the Cholesky sweep / Gradient computes it lazily  (default 1)
  *   "superpanel"   1..8    256-wide panels per trailing update (K = 256 * value)    (default 2)
+ *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
+ *                          mat.ConditionTolerance                                   (default 16)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 

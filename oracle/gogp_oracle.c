@@ -69,7 +69,7 @@ typedef struct gogp_oracle {
 } gogp_oracle;
 
 static int ntheta_noise(const gogp_desc *d) {
-  return d->noise_kind == GOGP_NOISE_UNIFORM ? 1 : 0;
+  return (d->noise_kind == GOGP_NOISE_UNIFORM || d->noise_kind == GOGP_NOISE_CONSTANT_PARAM) ? 1 : 0;
 }
 
 /* ---- similarity kernel: value and gradient w.r.t. [theta | xa | xb] -------
@@ -187,8 +187,9 @@ double gogp_oracle_noise(const gogp_desc *d, const double *theta_n, const double
   int nn = ntheta_noise(d);
   if (grad)
     for (int i = 0; i < nn + d->ndim; i++) grad[i] = 0.0;
-  if (d->noise_kind == GOGP_NOISE_CONSTANT) {
-    /* kernel/noise.go:27-30 */
+  if (d->noise_kind == GOGP_NOISE_CONSTANT || d->noise_kind == GOGP_NOISE_CONSTANT_PARAM) {
+    /* kernel/noise.go:27-30; tutorial/anynoise/kernel/kernel.go:31-33: a constant whatever
+     * the (single, unused) parameter is -- the tape gradient of a constant is 0 */
     return d->noise_std * d->noise_std;
   }
   /* kernel/noise.go:47-49 times the tutorial's constant factor */

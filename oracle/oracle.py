@@ -27,7 +27,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from gogp_amd.kernel import (CDesc, K_MATERN32, K_MATERN52, K_MATERN52_TEXTBOOK,
-                             K_NORMAL, K_PERIODIC, NOISE_CONSTANT, NOISE_UNIFORM,
+                             K_NORMAL, K_PERIODIC, NOISE_CONSTANT, NOISE_CONSTANT_PARAM, NOISE_UNIFORM,
                              SQRT3, SQRT5, build_desc)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -117,7 +117,7 @@ class Oracle:
         self.desc = build_desc(ndim, simil, noise)
         self.ndim = ndim
         self.ns = self.desc.ntheta_simil
-        self.nn = 1 if self.desc.noise_kind == NOISE_UNIFORM else 0
+        self.nn = 0 if self.desc.noise_kind == NOISE_CONSTANT else 1
         self._h = lib().gogp_oracle_new(ctypes.byref(self.desc))
         self._X = np.zeros((0, ndim))
         self._y = np.zeros((0,))
@@ -319,7 +319,7 @@ class FastOracle:
         self.desc = build_desc(ndim, simil, noise)
         self.ndim = ndim
         self.ns = self.desc.ntheta_simil
-        self.nn = 1 if self.desc.noise_kind == NOISE_UNIFORM else 0
+        self.nn = 0 if self.desc.noise_kind == NOISE_CONSTANT else 1
         self.block = block
         self.use_c = use_c
         self.X = np.zeros((0, ndim))
@@ -332,7 +332,7 @@ class FastOracle:
         self.Y = _arr(y).reshape(-1)
 
     def _noise_var(self, tn):
-        if self.desc.noise_kind == NOISE_CONSTANT:
+        if self.desc.noise_kind in (NOISE_CONSTANT, NOISE_CONSTANT_PARAM):
             return self.desc.noise_std ** 2
         return self.desc.noise_scale * tn[0] ** 2
 
@@ -409,9 +409,9 @@ class FastOracle:
                 for p in range(self.ns):
                     g[p] += 0.5 * float((W * dK[p]).sum())
             trW = float(a @ a) - float(np.trace(Kinv))
-        if self.nn:
+        if self.nn and self.desc.noise_kind == NOISE_UNIFORM:
             g[self.ns] = 0.5 * trW * 2.0 * self.desc.noise_scale * self.tn[0] ** 2
-        return g
+        return g  # NOISE_CONSTANT_PARAM: K does not depend on the parameter, component 0
 
     def Produce(self, Z):
         import scipy.linalg as sla

@@ -38,10 +38,24 @@ int main() {
         std::printf("produce mismatch %d: %g %g\n", i, mu[i], sigma[i]);
         return 1;
       }
+    if (gp.Alpha.size() != 2) return 1;  // refreshed by Absorb (gp/gp.go:35-36)
     gogp::GP g2(normal_desc(GOGP_NOISE_UNIFORM, 0.0));
-    g2.X = {{-1.0}, {-1.0}};  // x = [1, 1 | -1, -1 | 1, 0]
-    g2.Y = {1.0, 0.0};
+    g2.SetData({{-1.0}, {-1.0}}, {1.0, 0.0});  // x = [1, 1 | -1, -1 | 1, 0]
     const double ll = g2.Observe({1.0, 1.0});
+    const std::vector<double> a1 = g2.Alpha;
+    // hyperparameter steps on resident data: no upload, Alpha follows
+    const double llb = g2.Observe({0.7, 1.2});
+    if (llb == ll || g2.Alpha == a1) return 1;
+    if (g2.Observe({1.0, 1.0}) != ll || g2.Alpha != a1) return 1;
+    // in-place edit of Y + Touch(): the change reaches the device
+    g2.Y[1] = 0.5;
+    g2.Touch();
+    if (g2.Observe({1.0, 1.0}) == ll) return 1;
+    g2.Y[1] = 0.0;
+    g2.Touch();
+    if (g2.Observe({1.0, 1.0}) != ll) return 1;
+    const std::vector<double> Lf = g2.Factor();
+    if (Lf.size() != 4 || Lf[1] != 0.0 || !(Lf[0] > 0.0)) return 1;
     if (std::fabs(ll - (-4.018110)) >= 1e-6) {
       std::printf("lml mismatch: %.9f\n", ll);
       return 1;

@@ -512,6 +512,84 @@ def test_schedule_options_same_results(gpmod, opts, n):
     ref.close()
 
 
+def test_anynoise_constant_noise_with_parameter(gpmod):
+    """tutorial/anynoise/kernel/kernel.go:26-35: constant 1e-5 noise variance that still owns one
+    parameter (NTheta() == 1) which K does not depend on: its gradient component is exactly 0
+    and the LML does not move with it; hyperparameters-only and full (withObs) forms."""
+    from cases import ANYNOISE
+    from oracle.oracle import Oracle
+    name, D, simil, noise, ts, tn = ANYNOISE
+    g, o = _check_against(gpmod, Oracle, name, D, simil, noise, ts, tn, n=40, m=7, seed=11)
+    x = np.log(np.array(ts + tn))
+    lml = g.Observe(x)
+    grad = g.Gradient()
+    assert grad[2] == 0.0 and o.Gradient()[2] == 0.0
+    x2 = x.copy()
+    x2[2] += 1.7
+    assert g.Observe(x2) == lml
+    # full form, as the anynoise case study drives it (tutorial/tutorial.go:101-108)
+    rng = np.random.default_rng(3)
+    X, y = _data(rng, 12, D)
+    xf = np.concatenate([x, X.reshape(-1), y])
+    gf = gpmod.GP(D, simil, noise)
+    of = Oracle(D, simil, noise)
+    assert abs(gf.Observe(xf) - of.Observe(xf)) <= 1e-9 * max(1.0, abs(of.Observe(xf)))
+    np.testing.assert_allclose(gf.Gradient(), of.Gradient(), rtol=1e-6, atol=1e-7)
+
+
+def test_config1_barebones_recipe_64_rows(gpmod):
+    """BASELINE configs[0] as worded: 1-D Normal kernel, N = 64 rows made by the recipe of the
+    reference's tutorial/data/barebones.csv (x = i*pi/10, y = sin x + noise); HIP path vs the
+    faithful oracle (the 20-row file itself with the tutorial's c*Matern32 kernel is
+    test_barebones_csv_config1)."""
+    from gogp_amd import configs
+    from oracle.oracle import Oracle
+    wl = configs.workload(1)
+    X, y = wl.inputs()
+    assert X.shape == (64, 1)
+    g = gpmod.GP(1, wl.simil, wl.noise, X=X, Y=y)
+    o = Oracle(1, wl.simil, wl.noise)
+    o.set_data(X, y)
+    for k in range(3):
+        x = wl.log_theta(k)
+        lml, lml_o = g.Observe(x), o.Observe(x)
+        assert abs(lml - lml_o) <= 1e-9 * max(1.0, abs(lml_o))
+        np.testing.assert_allclose(g.Gradient(), o.Gradient(), rtol=1e-7, atol=1e-8)
+    Z = wl.test_points(16)
+    mu, sg = g.Produce(Z)
+    mu_o, sg_o = o.Produce(Z)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sg, sg_o, rtol=1e-6, atol=1e-8)
+
+
+def test_condition_error_like_gonum(gpmod):
+    """gonum's Cholesky solves return a Condition error above mat.ConditionTolerance (1e16),
+    which gp/gp.go:233-236 passes on; here (max L_ii / min L_ii)^2 is compared with the limit.
+    With the limit lowered an ordinary matrix trips it deterministically: the error is raised
+    AFTER the state was stored (as gonum fills the result and returns the error)."""
+    rng = np.random.default_rng(59)
+    n, D = 300, 2
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    x = np.log([1.0, 0.6, 0.05])
+    ref = gpmod.GP(D, simil, noise, X=X, Y=y)
+    lml_ref, alpha_ref = ref.Observe(x), ref.Alpha
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    assert g.Observe(x) == lml_ref  # default limit 1e16: fine
+    g.set_option("cond_limit_log10", 1)
+    with pytest.raises(gpmod.ConditionError):
+        g.Observe(x)
+    assert g.LML() == lml_ref
+    np.testing.assert_array_equal(g.Alpha, alpha_ref)
+    np.testing.assert_array_equal(g.Gradient(), ref.Gradient())
+    g.ThetaSimil, g.ThetaNoise = list(np.exp(x[:2])), list(np.exp(x[2:]))
+    with pytest.raises(gpmod.ConditionError):
+        g.Absorb(X, y)
+    g.set_option("cond_limit_log10", 16)
+    g.Absorb(X, y)
+    assert g.LML() == lml_ref
+
+
 def test_observe_gradient_batch_matches_single_calls(gpmod):
     """k candidates evaluated at once (one host thread per handle) give bit for bit what the
     same handles return one at a time."""

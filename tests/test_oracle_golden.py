@@ -253,3 +253,35 @@ def test_oracle_vectors_c_restatements(golden_dir):
             grad = o.Gradient()
             mu, sigma = o.Produce(Z)
             _assert_vector(v, lml, grad, mu, sigma, rtol=1e-9)
+
+
+def test_oracle_constant_noise_with_parameter():
+    """The anynoise noise kernel (tutorial/anynoise/kernel/kernel.go:26-35) in the oracle: one
+    parameter, constant value; gradient by the reference's own finite-difference recipe
+    (gp/gp_test.go:168-171,242-252) with a central difference, both oracle flavours agree."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cases import ANYNOISE
+    from oracle.oracle import FastOracle, Oracle
+    name, D, simil, noise, ts, tn = ANYNOISE
+    assert noise.NTheta() == 1 and noise.Observe([0.3, 1.0]) == pytest.approx(1e-5)
+    rng = np.random.default_rng(2)
+    X = rng.uniform(0, 1, (15, D))
+    y = np.sin(4 * X[:, 0]) + 0.1 * rng.normal(size=15)
+    x = np.log(np.array(ts + tn))
+    o, f = Oracle(D, simil, noise), FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    f.set_data(X, y)
+    ll = o.Observe(x)
+    g = o.Gradient()
+    assert abs(f.Observe(x) - ll) < 1e-9
+    np.testing.assert_allclose(f.Gradient(), g, rtol=1e-7, atol=1e-9)
+    assert g[2] == 0.0
+    # K has cond ~ 1e5 / 1e-5 here: a forward difference with the reference's dx = 1e-8 is
+    # dominated by rounding, so use a central difference and a relative tolerance
+    for j in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[j] += 1e-5
+        xm[j] -= 1e-5
+        fd = (o.Observe(xp) - o.Observe(xm)) / 2e-5
+        assert abs(g[j] - fd) <= 1e-4 * max(1.0, abs(g[j])), (j, g[j], fd)
