@@ -102,6 +102,6 @@ def workload(config: int, nobs: Optional[int] = None, ndim: Optional[int] = None
         ls = math.sqrt(D / 6.0) * (1.0 + np.arange(D) / (2.0 * D))
         return Workload(5, "BASELINE configs[4]: ARD-RBF, N=%d D=%d" % (N, D),
                         N, D, kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise,
-                        np.concatenate([[1.0], ls, [0.1]]), "f64", True,
+                        np.concatenate([[1.0], ls, [0.1]]), "f32", True,
                         "c*ARD-RBF(l_1..l_D) + sigma^2 I", SEED0 + 4)
     raise ValueError("config must be 1..5")

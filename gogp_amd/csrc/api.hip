@@ -183,6 +183,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   free_n_buffers(h);
   free_m_buffers(h);
   (void)hipFree(h->scalars);
+  (void)hipFree(h->dscr);
   (void)hipFree(h->info);
   (void)hipFree(h->gout);
   (void)hipFree(h->devP);
@@ -232,6 +233,7 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = acquire_streams(h, device);
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&h->dscr, (size_t)3 * PANEL * PANEL * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->devP, sizeof(DevParams));
@@ -257,12 +259,12 @@ static int ensure_n(gogp_handle *h, int64_t n) {
   h->trtri_done = false;
   if (npad > h->cap_npad) {
     free_n_buffers(h);
-    const size_t nn = (size_t)npad * (size_t)npad * sizeof(double);
+    const size_t nn = (size_t)npad * (size_t)npad * h->esz();  // matrices: float on the fp32 path
     HIPCHK(h, hipMalloc(&h->dX, (size_t)npad * h->D * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->bufA, nn));
     HIPCHK(h, hipMalloc(&h->bufL, nn));
-    HIPCHK(h, hipMalloc(&h->Dinv, (size_t)(npad / PANEL) * PANEL * PANEL * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->Dinv, (size_t)(npad / PANEL) * PANEL * PANEL * h->esz()));
     HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->w, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
@@ -350,7 +352,7 @@ static int ensure_y(gogp_handle *h) {
   h->bufY = nullptr;
   h->cap_y = 0;
   const int64_t cap = std::max(h->npad, h->cap_npad);
-  HIPCHK(h, hipMalloc(&h->bufY, (size_t)cap * (size_t)cap * sizeof(double)));
+  HIPCHK(h, hipMalloc(&h->bufY, (size_t)cap * (size_t)cap * h->esz()));
   h->cap_y = cap;
   return GOGP_OK;
 }
@@ -365,9 +367,39 @@ static int ensure_y(gogp_handle *h) {
 // R occupies the strictly upper 256-block triangle of bufA (zero-initialised),
 // which the Cholesky sweep never touches: the step only needs the panels of L it
 // names and their diagonal inverses, so it runs right behind their factorisation.
+// One 256x256 diagonal block: factor + dense inverse (diag256.hip, always fp64 arithmetic).  On
+// the fp32 path the block is widened into fp64 scratch, factored and inverted there, and the
+// factor and the inverse are rounded to float once; the log-determinant is accumulated from
+// the fp64 factor (scalars[5]).
+static void diag_block(gogp_handle *h, hipStream_t sp, const double *A, int64_t ld, double *L, int64_t ldl,
+                       double *Dp, int64_t c0) {
+  launch_diag256(sp, A, ld, L, ldl, Dp, c0, h->n, h->info);
+}
+static void diag_block(gogp_handle *h, hipStream_t sp, const float *A, int64_t ld, float *L, int64_t ldl,
+                       float *Dp, int64_t c0) {
+  double *A64 = h->dscr, *L64 = h->dscr + PANEL * PANEL, *D64 = h->dscr + 2 * PANEL * PANEL;
+  launch_convert_block(sp, A, ld, A64, PANEL, PANEL, PANEL);
+  launch_diag256(sp, A64, PANEL, L64, PANEL, D64, c0, h->n, h->info);
+  launch_convert_block(sp, L64, PANEL, L, ldl, PANEL, PANEL);
+  launch_convert_block(sp, D64, PANEL, Dp, PANEL, PANEL, PANEL);
+  launch_logdet_block(sp, L64, PANEL, c0, h->n, PANEL, h->scalars + 5);
+}
+static void diag_inv_only(gogp_handle *h, hipStream_t s, const double *L, int64_t ld, double *Dp) {
+  (void)h;
+  launch_diag256_inv_only(s, L, ld, Dp);
+}
+static void diag_inv_only(gogp_handle *h, hipStream_t s, const float *L, int64_t ld, float *Dp) {
+  double *L64 = h->dscr + PANEL * PANEL, *D64 = h->dscr + 2 * PANEL * PANEL;
+  launch_convert_block(s, L, ld, L64, PANEL, PANEL, PANEL);
+  launch_diag256_inv_only(s, L64, PANEL, D64);
+  launch_convert_block(s, D64, PANEL, Dp, PANEL, PANEL, PANEL);
+}
+
+template <class T>
 static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hipStream_t s2) {
   const int64_t npad = h->npad, ld = npad;
-  double *R = h->bufA, *Y = h->bufY, *L = h->bufL;
+  T *R = reinterpret_cast<T *>(h->bufA), *Y = reinterpret_cast<T *>(h->bufY),
+    *L = reinterpret_cast<T *>(h->bufL);
   GemmProfile *pf = &h->prof;
   const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
   // R[0:C0, C0:CE] is final: its last update (the previous super-step's next-columns update)
@@ -375,18 +407,18 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
   for (int q = 0; q < nsub; ++q) {
     const int p = P0 + q;
     const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
-    const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+    const T *Dp = reinterpret_cast<const T *>(h->Dinv) + (size_t)p * PANEL * PANEL;
     launch_ydiag(st, Dp, Y + c0 * ld + c0, ld);
     if (c2 < CE)  // block below the diagonal inside the super-panel: part of the K range
       launch_zero_block(st, Y + c2 * ld + c0, ld, CE - c2, PANEL);
     if (c0 > 0)
-      launch_dgemm_nt(st, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
+      launch_gemm_nt(st, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
                       Y + c0, ld, pf);
     if (c2 < CE) {  // same binary grouping as the Cholesky sweep's updates inside a super-panel
       const int done = q + 1, grp = done & -done;
       const int64_t k0 = c2 - (int64_t)grp * PANEL;
       const int64_t ce = (c2 + (int64_t)grp * PANEL < CE) ? c2 + (int64_t)grp * PANEL : CE;
-      launch_dgemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((ce - c2) / TILE), (int64_t)grp * PANEL,
+      launch_gemm_nt(st, GEMM_RECT, (int)(c2 / TILE), (int)((ce - c2) / TILE), (int64_t)grp * PANEL,
                       -1.0, Y + k0, ld, L + c2 * ld + k0, ld, 1.0, R + c2, ld, pf);
     }
   }
@@ -400,18 +432,19 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
     // event hop on the chain); they were last touched by the previous super-step's bulk update.
     if (P0 > 0 && st != s2)
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (P0 - h->superpanel) + 3), 0);
-    launch_dgemm_nt(st, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
+    launch_gemm_nt(st, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
                     R + CE, ld, pf);
     if (nt > ntn) {
       const int64_t C3 = CE + (int64_t)ntn * TILE;
-      launch_dgemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
+      launch_gemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
                       R + C3, ld, pf);
     }
     (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);  // bulk R update of super-step P0 done
   }
 }
 
-static int factorize(gogp_handle *h, bool eager) {
+template <class T>
+static int factorize_t(gogp_handle *h, bool eager) {
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
   // without lookahead everything runs in order on the main stream
@@ -443,7 +476,7 @@ static int factorize(gogp_handle *h, bool eager) {
   // starts ~30 us later instead of after the whole 0.5 ms build -- the rest on the main stream
   {
     AuxTimer tm(h, GOGP_PROF_GRAM, s);  // the main-stream part: all but the first block columns
-    launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, h->bufA, ld,
+    launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, reinterpret_cast<T *>(h->bufA), ld,
                             (int64_t)h->superpanel * PANEL);
   }
   (void)hipEventRecord(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
@@ -452,13 +485,15 @@ static int factorize(gogp_handle *h, bool eager) {
     // R := 0 on the strictly upper block triangle (after whatever used bufA last)
     (void)hipStreamWaitEvent(s2, ev(h, EV_GRAM), 0);
     (void)hipStreamWaitEvent(st, ev(h, EV_GRAM), 0);
-    launch_zero_upper_blocks(s2, h->bufA, ld, npad);
+    launch_zero_upper_blocks(s2, reinterpret_cast<T *>(h->bufA), ld, npad);
     order(h, EV_INIT, s2, st);  // st also writes R (updates inside a super-panel)
   }
-  double *A = h->bufA, *L = h->bufL;
+  T *A = reinterpret_cast<T *>(h->bufA), *L = reinterpret_cast<T *>(h->bufL);
+  T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
   const int SW = h->superpanel;
+  if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
   HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
   // The forward substitution z = L^-1 y needs each panel once it is final and nothing
@@ -476,13 +511,13 @@ static int factorize(gogp_handle *h, bool eager) {
     for (int q = 0; q < nsub; ++q) {
       const int p = P0 + q;
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
-      double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
+      T *Dp = Dinv + (size_t)p * PANEL * PANEL;
       // 256x256 diagonal block: factor + dense inverse, one workgroup
-      launch_diag256(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0, h->n, h->info);
+      diag_block(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
       const int mt2 = (int)((npad - c2) / TILE);
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
       if (mt2 > 0)
-        launch_dgemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
+        launch_gemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
                         L + c2 * ld + c0, ld, pf);
       // Updates inside the super-panel, grouped like a binary counter: after panel q the
       // next g = lowbit(q+1) block columns receive the LAST g panels at once (K = 256 g), each
@@ -494,7 +529,7 @@ static int factorize(gogp_handle *h, bool eager) {
         const int done = q + 1, grp = done & -done;
         const int64_t k0 = c2 - (int64_t)grp * PANEL;
         const int64_t ce = (c2 + (int64_t)grp * PANEL < CE) ? c2 + (int64_t)grp * PANEL : CE;
-        launch_dgemm_nt(sp, GEMM_TRAP, (int)((npad - c2) / TILE), (int)((ce - c2) / TILE),
+        launch_gemm_nt(sp, GEMM_TRAP, (int)((npad - c2) / TILE), (int)((ce - c2) / TILE),
                         (int64_t)grp * PANEL, -1.0, L + c2 * ld + k0, ld, L + c2 * ld + k0, ld, 1.0,
                         A + c2 * ld + c2, ld, pf);
       }
@@ -502,7 +537,7 @@ static int factorize(gogp_handle *h, bool eager) {
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
     if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
     for (int q = 0; q < nsub; ++q)
-      launch_trsv_fwd_step(sz, L, ld, h->Dinv, P0 + q, npanel, h->w, h->z);
+      launch_trsv_fwd_step(sz, L, ld, Dinv, P0 + q, npanel, h->w, h->z);
     // ---- trailing update, rank nsub*256 ------------------------------------------------------
     const int mtE = (int)((npad - CE) / TILE);
     if (mtE > 0) {
@@ -517,12 +552,12 @@ static int factorize(gogp_handle *h, bool eager) {
       // ONE trapezoid launch for all of them (rows CE.., columns CE .. CE + ntn*128, the
       // strictly upper 256-blocks -- R of the triangular inverse -- skipped): separate
       // launches would run one after the other on this in-order stream
-      launch_dgemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
+      launch_gemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
                       1.0, A + CE * ld + CE, ld, pf);
       // the rest of the trailing matrix, lower tiles only (main stream)
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
-        launch_dgemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
+        launch_gemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
       }
       (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
@@ -530,7 +565,7 @@ static int factorize(gogp_handle *h, bool eager) {
     // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
-      trtri_superstep(h, P0, nsub, st, s2);
+      trtri_superstep<T>(h, P0, nsub, st, s2);
     }
   }
   if (eager) {
@@ -540,13 +575,13 @@ static int factorize(gogp_handle *h, bool eager) {
   }
   order(h, EV_FWD, sz, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
   if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
     // triangular inverse is complete (st), instead of 64 dependent substitution steps
     (void)hipStreamWaitEvent(st, ev(h, EV_FWD), 0);
-    launch_alpha_from_y(st, h->bufY, ld, h->z, npad, h->alpha);
+    launch_alpha_from_y(st, reinterpret_cast<const T *>(h->bufY), ld, h->z, npad, h->alpha);
     (void)hipEventRecord(ev(h, EV_ALPHA), st);
     (void)hipEventRecord(ev(h, EV_TRTRI), st);
   } else {
@@ -554,7 +589,7 @@ static int factorize(gogp_handle *h, bool eager) {
     if (sz != sp) (void)hipStreamWaitEvent(sp, ev(h, EV_FWD), 0);
     HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
     for (int b = npanel - 1; b >= 0; --b)
-      launch_trsv_bwd_step(sp, L, ld, h->Dinv, b, npanel, h->w, h->alpha);
+      launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->w, h->alpha);
     (void)hipEventRecord(ev(h, EV_ALPHA), sp);
   }
   h->alpha_pending = true;
@@ -576,7 +611,8 @@ static int factorize(gogp_handle *h, bool eager) {
     h->err = buf;
     return GOGP_ENOTPD;
   }
-  const double logdet = h->hscal[0], ztz = h->hscal[1];
+  // fp32 path: the log-determinant summed from the fp64 diagonal-block factors
+  const double logdet = sizeof(T) == 4 ? h->hscal[5] : h->hscal[0], ztz = h->hscal[1];
   // gp/gp.go:244-253
   h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
   h->factored = true;
@@ -595,6 +631,10 @@ static int factorize(gogp_handle *h, bool eager) {
     return GOGP_ECOND;
   }
   return GOGP_OK;
+}
+
+static int factorize(gogp_handle *h, bool eager) {
+  return h->prec == 32 ? factorize_t<float>(h, eager) : factorize_t<double>(h, eager);
 }
 
 // alpha is computed by factorize() on the panel stream; make the main stream
@@ -701,7 +741,8 @@ extern "C" int gogp_lml(gogp_handle *h, double *lml) {
 }
 
 // ---- gradient --------------------------------------------------------------------------------
-static int compute_kinv(gogp_handle *h) {
+template <class T>
+static int compute_kinv_t(gogp_handle *h) {
   if (h->have_kinv) return GOGP_OK;
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
@@ -711,11 +752,11 @@ static int compute_kinv(gogp_handle *h) {
     hipStream_t sp = h->lookahead ? h->sp : h->s;
     const int rcy = ensure_y(h);
     if (rcy != GOGP_OK) return rcy;
-    launch_zero_upper_blocks(s, h->bufA, ld, npad);
+    launch_zero_upper_blocks(s, reinterpret_cast<T *>(h->bufA), ld, npad);
     order(h, EV_INIT, s, sp);
     const int npanel = (int)(npad / PANEL);
     for (int P0 = 0; P0 < npanel; P0 += h->superpanel)
-      trtri_superstep(h, P0, (npanel - P0 < h->superpanel) ? npanel - P0 : h->superpanel, sp, s);
+      trtri_superstep<T>(h, P0, (npanel - P0 < h->superpanel) ? npanel - P0 : h->superpanel, sp, s);
     order(h, EV_TRTRI, sp, s);
     h->trtri_done = true;
   } else if (h->trtri_pending) {
@@ -723,10 +764,13 @@ static int compute_kinv(gogp_handle *h) {
   }
   h->trtri_pending = false;
   // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
-  launch_dgemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, h->bufY, ld, h->bufY, ld, 0.0,
-                  h->bufA, ld, pf);
+  launch_gemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, reinterpret_cast<const T *>(h->bufY), ld,
+                 reinterpret_cast<const T *>(h->bufY), ld, 0.0, reinterpret_cast<T *>(h->bufA), ld, pf);
   h->have_kinv = true;
   return GOGP_OK;
+}
+static int compute_kinv(gogp_handle *h) {
+  return h->prec == 32 ? compute_kinv_t<float>(h) : compute_kinv_t<double>(h);
 }
 
 static int64_t grad_len(const gogp_handle *h) {
@@ -742,6 +786,8 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
   HIPCHK(h, hipSetDevice(h->device));
   if (h->dist && h->with_obs)
     return fail(h, GOGP_EARG, "sharded evaluation: the full Observe form is not supported");
+  if (h->prec == 32 && h->with_obs)
+    return fail(h, GOGP_EARG, "fp32 path: the full Observe form is not supported");
   if (!h->grad_valid && h->dist) {
     // sharded: every rank reduces its own tiles of K^-1, one all-reduce of the slot sums
     int rc = gogp_dist_gradient_sums(h, h->hscal + 16);
@@ -754,8 +800,12 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
     hipStream_t s = h->s;
     {
       AuxTimer tm(h, GOGP_PROF_GRAD, s);
-      launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
-                         h->npad, h->gpart, h->gout);
+      if (h->prec == 32)
+        launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha,
+                           reinterpret_cast<const float *>(h->bufA), h->npad, h->n, h->npad, h->gpart, h->gout);
+      else
+        launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
+                           h->npad, h->gpart, h->gout);
     }
     HIPCHK(h, hipMemcpyAsync(h->hscal + 16, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -833,13 +883,42 @@ static int ensure_m(gogp_handle *h, int64_t m, int64_t mpad) {
     HIPCHK(h, hipMalloc(&h->dZ, (size_t)std::max<int64_t>(m, 1) * h->D * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->pvec, (size_t)4 * std::max<int64_t>(mpad, 1) * sizeof(double)));
     if (h->npad > 0) {
-      HIPCHK(h, hipMalloc(&h->KsT, (size_t)mpad * h->npad * sizeof(double)));
-      HIPCHK(h, hipMalloc(&h->Vt, (size_t)mpad * h->npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->KsT, (size_t)mpad * h->npad * h->esz()));
+      HIPCHK(h, hipMalloc(&h->Vt, (size_t)mpad * h->npad * h->esz()));
     }
     h->cap_m = m;
     h->cap_mp_npad = mpad * h->npad;
   }
   return GOGP_OK;
+}
+
+// Kstar, mean and the blocked solve of Produce on matrices of element type T
+template <class T>
+static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad, double *dmu, double *dq) {
+  const int64_t npad = h->npad, ld = npad;
+  T *R = reinterpret_cast<T *>(h->KsT), *V = reinterpret_cast<T *>(h->Vt);
+  const T *L = reinterpret_cast<const T *>(h->bufL), *Dinv = reinterpret_cast<const T *>(h->Dinv);
+  {
+    AuxTimer tm(h, GOGP_PROF_CROSS, s);
+    launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, R, ld);  // gp/gp.go:322-332
+  }
+  // mean = Kstar^T alpha (gp/gp.go:335)
+  launch_rownorm_dot(s, R, ld, h->alpha, npad, m, dmu, nullptr);
+  // V^T = Kstar^T L^-T by blocked substitution on the GEMM kernel
+  GemmProfile *pf = nullptr;  // Produce launches are not part of the Observe+Gradient metric
+  const int mt = (int)(mpad / TILE);
+  const int npanel = (int)(npad / PANEL);
+  for (int p = 0; p < npanel; ++p) {
+    const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
+    const T *Dp = Dinv + (size_t)p * PANEL * PANEL;
+    launch_gemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf);
+    const int nt = (int)((npad - c2) / TILE);
+    if (nt > 0)
+      launch_gemm_nt(s, GEMM_RECT, mt, nt, PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld, 1.0,
+                     R + c2, ld, pf);
+  }
+  // (Kstar^T K^-1 Kstar)_jj = |V_j|^2 : only the diagonal of gp/gp.go:341-342 is read (:356)
+  launch_rownorm_dot(s, V, ld, nullptr, npad, m, nullptr, dq);
 }
 
 extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *mu,
@@ -871,30 +950,10 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   }
   rc = ensure_alpha(h);
   if (rc != GOGP_OK) return rc;
-  const int64_t npad = h->npad, ld = npad;
-  double *R = h->KsT, *V = h->Vt, *L = h->bufL;
-  {
-    AuxTimer tm(h, GOGP_PROF_CROSS, s);
-    launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, R, ld);  // gp/gp.go:322-332
-  }
-  // mean = Kstar^T alpha (gp/gp.go:335)
-  launch_rownorm_dot(s, R, ld, h->alpha, npad, m, dmu, nullptr);
-  // V^T = Kstar^T L^-T by blocked substitution on the GEMM kernel
-  GemmProfile *pf = nullptr;  // Produce launches are not part of the Observe+Gradient metric
-  const int mt = (int)(mpad / TILE);
-  const int npanel = (int)(npad / PANEL);
-  for (int p = 0; p < npanel; ++p) {
-    const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE, c2 = c0 + PANEL;
-    const double *Dp = h->Dinv + (size_t)p * PANEL * PANEL;
-    (void)c1;
-    launch_dgemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf);
-    const int nt = (int)((npad - c2) / TILE);
-    if (nt > 0)
-      launch_dgemm_nt(s, GEMM_RECT, mt, nt, PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld, 1.0,
-                      R + c2, ld, pf);
-  }
-  // (Kstar^T K^-1 Kstar)_jj = |V_j|^2 : only the diagonal of gp/gp.go:341-342 is read (:356)
-  launch_rownorm_dot(s, V, ld, nullptr, npad, m, nullptr, dq);
+  if (h->prec == 32)
+    produce_solve_t<float>(h, s, m, mpad, dmu, dq);
+  else
+    produce_solve_t<double>(h, s, m, mpad, dmu, dq);
   launch_sigma(s, prior, dq, m, dsig);
   HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(sigma, dsig, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -924,7 +983,10 @@ extern "C" int gogp_get_factor(gogp_handle *h, double *Lout) {
   HIPCHK(h, hipSetDevice(h->device));
   double *tmp = nullptr;
   HIPCHK(h, hipMalloc(&tmp, (size_t)h->n * h->n * sizeof(double)));
-  launch_extract_lower(h->s, h->bufL, h->npad, h->n, tmp);
+  if (h->prec == 32)
+    launch_extract_lower(h->s, reinterpret_cast<const float *>(h->bufL), h->npad, h->n, tmp);
+  else
+    launch_extract_lower(h->s, h->bufL, h->npad, h->n, tmp);
   hipError_t e = hipMemcpyAsync(Lout, tmp, (size_t)h->n * h->n * sizeof(double),
                                 hipMemcpyDeviceToHost, h->s);
   if (e == hipSuccess) e = hipStreamSynchronize(h->s);
@@ -943,11 +1005,18 @@ extern "C" int gogp_get_factor_rows(gogp_handle *h, const int64_t *rows, int64_t
   const int64_t n = h->n;
   for (int64_t r = 0; r < nrows; ++r)
     if (rows[r] < 0 || rows[r] >= n) return fail(h, GOGP_EARG, "get_factor_rows: row out of range");
+  std::vector<float> tmp32(h->prec == 32 ? (size_t)n : 0);
   for (int64_t r = 0; r < nrows; ++r) {
     const int64_t i = rows[r];
     double *o = out + r * n;
-    HIPCHK(h, hipMemcpyAsync(o, h->bufL + (size_t)i * h->npad, (size_t)(i + 1) * sizeof(double),
-                             hipMemcpyDeviceToHost, h->s));
+    if (h->prec == 32) {
+      HIPCHK(h, hipMemcpy(tmp32.data(), reinterpret_cast<const float *>(h->bufL) + (size_t)i * h->npad,
+                          (size_t)(i + 1) * sizeof(float), hipMemcpyDeviceToHost));
+      for (int64_t j = 0; j <= i; ++j) o[j] = (double)tmp32[(size_t)j];
+    } else {
+      HIPCHK(h, hipMemcpyAsync(o, h->bufL + (size_t)i * h->npad, (size_t)(i + 1) * sizeof(double),
+                               hipMemcpyDeviceToHost, h->s));
+    }
     for (int64_t j = i + 1; j < n; ++j) o[j] = 0.0;
   }
   HIPCHK(h, hipStreamSynchronize(h->s));
@@ -960,6 +1029,13 @@ extern "C" int gogp_get_factor_diag(gogp_handle *h, double *diag) {
   if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
   if (h->dist) return fail(h, GOGP_ESTATE, "L diagonal: not available on a sharded handle");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->prec == 32) {
+    std::vector<float> d32((size_t)h->n);
+    HIPCHK(h, hipMemcpy2D(d32.data(), sizeof(float), h->bufL, (size_t)(h->npad + 1) * sizeof(float),
+                          sizeof(float), (size_t)h->n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < h->n; ++i) diag[i] = (double)d32[(size_t)i];
+    return GOGP_OK;
+  }
   HIPCHK(h, hipMemcpy2DAsync(diag, sizeof(double), h->bufL, (size_t)(h->npad + 1) * sizeof(double),
                              sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->s));
   HIPCHK(h, hipStreamSynchronize(h->s));
@@ -990,10 +1066,18 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   HIPCHK(h, hipMalloc(&tmp, (size_t)n * n * sizeof(double)));
   hipError_t e = hipMemcpyAsync(tmp, Lin, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    launch_pack_lower(s, tmp, n, npad, h->bufL, npad);
-    for (int b = 0; b < (int)(npad / PANEL); ++b)
-      launch_diag256_inv_only(s, h->bufL + (size_t)b * PANEL * npad + (size_t)b * PANEL, npad,
-                              h->Dinv + (size_t)b * PANEL * PANEL);
+    if (h->prec == 32) {
+      float *L32 = reinterpret_cast<float *>(h->bufL), *D32 = reinterpret_cast<float *>(h->Dinv);
+      launch_pack_lower(s, tmp, n, npad, L32, npad);
+      for (int b = 0; b < (int)(npad / PANEL); ++b)
+        diag_inv_only(h, s, L32 + (size_t)b * PANEL * npad + (size_t)b * PANEL, npad,
+                      D32 + (size_t)b * PANEL * PANEL);
+    } else {
+      launch_pack_lower(s, tmp, n, npad, h->bufL, npad);
+      for (int b = 0; b < (int)(npad / PANEL); ++b)
+        diag_inv_only(h, s, h->bufL + (size_t)b * PANEL * npad + (size_t)b * PANEL, npad,
+                      h->Dinv + (size_t)b * PANEL * PANEL);
+    }
     e = hipMemsetAsync(h->alpha, 0, (size_t)npad * sizeof(double), s);
   }
   if (e == hipSuccess)
@@ -1006,7 +1090,11 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   h->have_alpha = true;
   h->alpha_pending = false;
   // LML of the restored state: -n/2 log 2pi - sum log L_ii - 1/2 y^T alpha
-  launch_lml_scalars(s, h->bufL, npad, h->alpha, h->dy, h->alpha, n, h->scalars);
+  if (h->prec == 32)
+    launch_lml_scalars(s, reinterpret_cast<const float *>(h->bufL), npad, h->alpha, h->dy, h->alpha, n,
+                       h->scalars);
+  else
+    launch_lml_scalars(s, h->bufL, npad, h->alpha, h->dy, h->alpha, n, h->scalars);
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   h->lml = -0.5 * (double)n * log(2 * M_PI) - 0.5 * h->hscal[0] - 0.5 * h->hscal[2];
@@ -1090,6 +1178,24 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   }
   if (strcmp(name, "eager") == 0) {
     h->eager = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "precision") == 0) {
+    // 64 (default): everything fp64.  32: the N x N matrices (K, L, Y, K^-1, block inverses) and
+    // the O(N^3) products in fp32 on v_mfma_f32_32x32x2_f32; inputs, kernel evaluation, diagonal
+    // blocks, vectors and all reductions stay fp64 (BASELINE config 5; DESIGN.md "fp32 path").
+    // Changes the buffers: the data must be set again afterwards.
+    if (value != 32 && value != 64) return fail(h, GOGP_EARG, "precision must be 32 or 64");
+    if (h->dist && value == 32) return fail(h, GOGP_EARG, "precision 32 is not available on a sharded handle");
+    if ((int)value != h->prec) {
+      HIPCHK(h, hipSetDevice(h->device));
+      for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+      free_n_buffers(h);
+      free_m_buffers(h);
+      h->prec = (int)value;
+      h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
+      h->trtri_done = h->trtri_pending = h->alpha_pending = false;
+    }
     return GOGP_OK;
   }
   if (strcmp(name, "cond_limit_log10") == 0) {  // gonum: mat.ConditionTolerance (a package variable), 1e16

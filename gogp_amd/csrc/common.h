@@ -84,6 +84,43 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
                      int64_t ldb, double beta, double *C, int64_t ldc,
                      GemmProfile *prof, const GemmGrid *grid = nullptr);
 
+// fp32 path (BASELINE config 5): the same launchers overloaded on the MATRIX element type.
+// Inputs, vectors (y, z, alpha) and every reduction stay fp64; only the N x N matrices
+// (K / L / Y / K^-1, the block inverses, the Produce workspaces) are float.
+void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha, const double *A,
+                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
+                    GemmProfile *prof, const GemmGrid *grid = nullptr);  // = launch_dgemm_nt
+void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha, const float *A,
+                    int64_t lda, const float *B, int64_t ldb, double beta, float *C, int64_t ldc,
+                    GemmProfile *prof, const GemmGrid *grid = nullptr);  // sgemm.hip
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, float *K, int64_t ld,
+                             int64_t wcols);
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, float *KsT, int64_t ld);
+void launch_trsv_fwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv, int b, int nblk,
+                          double *y, double *z);
+void launch_trsv_bwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv, int b, int nblk,
+                          double *zwork, double *alpha);
+void launch_lml_scalars(hipStream_t s, const float *L, int64_t ld, const double *z, const double *y,
+                        const double *alpha, int64_t n, double *scalars);
+void launch_alpha_from_y(hipStream_t s, const float *Y, int64_t ld, const double *z, int64_t npad,
+                         double *alpha);
+void launch_rownorm_dot(hipStream_t s, const float *V, int64_t ld, const double *vec, int64_t ncols,
+                        int64_t m, double *dot, double *sq);
+void launch_zero_upper_blocks(hipStream_t s, float *R, int64_t ld, int64_t npad);
+void launch_zero_block(hipStream_t s, float *B, int64_t ld, int64_t rows, int64_t cols);
+void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld);
+void launch_extract_lower(hipStream_t s, const float *L, int64_t ld, int64_t n, double *out);
+void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, float *L, int64_t ld);
+void launch_convert_block(hipStream_t s, const float *src, int64_t lds_, double *dst, int64_t ldd, int rows,
+                          int cols);
+void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float *dst, int64_t ldd, int rows,
+                          int cols);
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims, const double *X,
+                        const double *alpha, const float *Kinv, int64_t ld, int64_t n, int64_t npad,
+                        double *partials, double *out);
+
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
 // Local tiles (mrows x ncols) of a 2-D block-cyclic Gram matrix: tiles of the global lower

@@ -152,6 +152,10 @@ static int dist_init_common(gogp_handle *h, int rank, int nranks, int prow, int 
     delete tr;
     return fail(h, GOGP_EARG, "dist_init: the grid must be Pr x Pc = nranks with Pr dividing Pc");
   }
+  if (h->prec != 64) {
+    delete tr;
+    return fail(h, GOGP_EARG, "dist_init: a sharded handle computes in fp64 (precision 32 is single-GPU)");
+  }
   if (h->dist) gogp_dist_destroy(h);
   Dist2D *d = new Dist2D();
   d->rank = rank;

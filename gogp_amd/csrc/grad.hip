@@ -19,10 +19,11 @@ constexpr int GR_BLOCKS_MAX = 2048;
 
 // LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
 // grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
-template <int ARD_D, bool LOCAL>
+// KT: element type of K^-1 (float on the fp32 path; all sums are fp64 either way).
+template <int ARD_D, bool LOCAL, class KT>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
-    const double *__restrict__ alpha, const double *__restrict__ Kinv, long ld, long n, int nt,
+    const double *__restrict__ alpha, const KT *__restrict__ Kinv, long ld, long n, int nt,
     int ntiles, double *__restrict__ partials, int ntc, BlockMap map) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
       const int r = ty * 16 + rr;
       const long gi = r0 + r;
       if (gi < n && gj <= gi) {
-        const double w = ai[r] * ajv - Kinv[(lr0 + r) * ld + lc0 + tx];
+        const double w = ai[r] * ajv - (double)Kinv[(lr0 + r) * ld + lc0 + tx];
         const double wgt = (gj < gi) ? 2.0 * w : w;
         const double *ri = Ri + r * D;
         simil_grad_accum<ARD_D>(
@@ -136,15 +137,16 @@ int grad_reduce_blocks(int64_t npad) {
   return (int)(ntiles < GR_BLOCKS_MAX ? ntiles : GR_BLOCKS_MAX);
 }
 
-void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
-                        const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out) {
+template <class KT>
+static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                          const double *X, const double *alpha, const KT *Kinv, int64_t ld,
+                          int64_t n, int64_t npad, double *partials, double *out) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GR(AD)                                                                      \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                      Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap())
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
@@ -153,6 +155,16 @@ void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dim
   else GOGP_LAUNCH_GR(64);
 #undef GOGP_LAUNCH_GR
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+}
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                        int64_t n, int64_t npad, double *partials, double *out) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
+}
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const float *Kinv, int64_t ld,
+                        int64_t n, int64_t npad, double *partials, double *out) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
 }
 
 int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
@@ -169,7 +181,7 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD)                                                                       \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, true, double>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                      Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map)
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8);

@@ -17,11 +17,13 @@
 
 namespace gogp {
 
-template <bool CROSS>
+// T: element type of the output matrix (double, or float on the fp32 path: the kernel value
+// is computed in fp64 from the fp64 inputs and rounded once on store)
+template <bool CROSS, class T>
 __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__ Pp,
                                                    const double *__restrict__ Rsrc, long nrows,
                                                    const double *__restrict__ Csrc, long ncols,
-                                                   double *__restrict__ Out, long ld, int ntc,
+                                                   T *__restrict__ Out, long ld, int ntc,
                                                    int strip_w, int toff) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
     } else {
       k = (!CROSS && gi == gj) ? 1.0 : 0.0;
     }
-    Out[gi * ld + gj] = k;
+    Out[gi * ld + gj] = (T)k;
   }
 }
 
@@ -133,31 +135,47 @@ __global__ void prior_kernel(const DevParams *__restrict__ Pp, const double *__r
       P, [&](int d) { return z[d]; }, [&](int d) { return z[d]; });
 }
 
-void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
-                       int64_t n, int64_t npad, double *K, int64_t ld) {
+template <class T>
+static void gram_lower_t(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                         int64_t npad, T *K, int64_t ld) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL(gram_kernel<false>, dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
                      (long)n, K, (long)ld, nt, 0, 0);
+}
+void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t npad, double *K, int64_t ld) {
+  gram_lower_t(s, p, ndim, X, n, npad, K, ld);
 }
 
 // The same lower triangle in two launches: block columns [0, wcols) on `s_first` (the panel
 // chain can start on them while the rest is still being written), the remaining triangle on
 // `s_rest`.  wcols is a multiple of 64.
-void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
-                             const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
-                             int64_t wcols) {
+template <class T>
+static void gram_lower_split_t(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                               const double *X, int64_t n, int64_t npad, T *K, int64_t ld,
+                               int64_t wcols) {
   const int nt = (int)(npad / 64);
   int w = (int)(wcols / 64);
   if (w > nt) w = nt;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL(gram_kernel<false>, dim3(nt * w), dim3(256), lds, s_first, p, X, (long)n, X,
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nt * w), dim3(256), lds, s_first, p, X, (long)n, X,
                      (long)n, K, (long)ld, nt, w, 0);
   const int nr = nt - w;
   if (nr > 0)
-    hipLaunchKernelGGL(gram_kernel<false>, dim3(nr * (nr + 1) / 2), dim3(256), lds, s_rest, p, X,
+    hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nr * (nr + 1) / 2), dim3(256), lds, s_rest, p, X,
                        (long)n, X, (long)n, K, (long)ld, nt, 0, w);
+}
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
+                             int64_t wcols) {
+  gram_lower_split_t(s_first, s_rest, p, ndim, X, n, npad, K, ld, wcols);
+}
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, float *K, int64_t ld,
+                             int64_t wcols) {
+  gram_lower_split_t(s_first, s_rest, p, ndim, X, n, npad, K, ld, wcols);
 }
 
 void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -169,13 +187,21 @@ void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double
                      ntc, map);
 }
 
-void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
-                  int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT,
-                  int64_t ld) {
+template <class T>
+static void cross_t(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                    int64_t npad, const double *Z, int64_t m, int64_t mpad, T *KsT, int64_t ld) {
   const int ntr = (int)(mpad / 64), ntc = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL(gram_kernel<true>, dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
+  hipLaunchKernelGGL((gram_kernel<true, T>), dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
                      (long)n, KsT, (long)ld, ntc, 0, 0);
+}
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT, int64_t ld) {
+  cross_t(s, p, ndim, X, n, npad, Z, m, mpad, KsT, ld);
+}
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, float *KsT, int64_t ld) {
+  cross_t(s, p, ndim, X, n, npad, Z, m, mpad, KsT, ld);
 }
 
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,

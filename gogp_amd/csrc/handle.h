@@ -25,6 +25,9 @@ struct gogp_handle {
   double *bufA = nullptr, *bufL = nullptr, *bufY = nullptr, *Dinv = nullptr;
   double *z = nullptr, *w = nullptr, *alpha = nullptr;
   double *scalars = nullptr;  // 8 doubles
+  double *dscr = nullptr;     // fp32 path: fp64 scratch of the diagonal-block kernel (3 x 256 x 256)
+  int prec = 64;              // 64: fp64 throughout; 32: N x N matrices and O(N^3) products in fp32
+  size_t esz() const { return prec == 32 ? sizeof(float) : sizeof(double); }
   long long *info = nullptr;
   double *gpart = nullptr, *gout = nullptr;
   DevParams *devP = nullptr;

@@ -9,6 +9,40 @@
 
 namespace gogp {
 
+// 8 consecutive matrix elements as doubles (16-B loads for both element types)
+__device__ __forceinline__ void load8(const double *p, double *o) {
+  const double2 *q = reinterpret_cast<const double2 *>(p);
+  const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
+}
+__device__ __forceinline__ void load8(const float *p, double *o) {
+  const float4 *q = reinterpret_cast<const float4 *>(p);
+  const float4 a = q[0], b = q[1];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void load2(const double *p, double &a, double &b) {
+  const double2 v = *reinterpret_cast<const double2 *>(p);
+  a = v.x;
+  b = v.y;
+}
+__device__ __forceinline__ void load2(const float *p, double &a, double &b) {
+  const float2 v = *reinterpret_cast<const float2 *>(p);
+  a = v.x;
+  b = v.y;
+}
+__device__ __forceinline__ void store2zero(double *p) {
+  double2 v;
+  v.x = 0.0;
+  v.y = 0.0;
+  *reinterpret_cast<double2 *>(p) = v;
+}
+__device__ __forceinline__ void store2zero(float *p) {
+  float2 v;
+  v.x = 0.0f;
+  v.y = 0.0f;
+  *reinterpret_cast<float2 *>(p) = v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -19,7 +53,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // 256-thread workgroup, v[256] and res[128] in LDS.  32 lanes share a row
 // (8 consecutive columns each: 2 KB contiguous per row), 2 rows per
 // wave-iteration, 5 xor-shuffles per pair of rows.
-__device__ __forceinline__ void matvec_128x256(const double *__restrict__ M, long ldm,
+template <class T>
+__device__ __forceinline__ void matvec_128x256(const T *__restrict__ M, long ldm,
                                                const double *v, double *res) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rsub = lane >> 5, cg = lane & 31;
@@ -29,10 +64,10 @@ __device__ __forceinline__ void matvec_128x256(const double *__restrict__ M, lon
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
     const int r = wid * 32 + it * 2 + rsub;
-    const double2 *mp = reinterpret_cast<const double2 *>(M + (long)r * ldm + cg * 8);
-    const double2 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
-    double q = m0.x * vv[0] + m0.y * vv[1] + m1.x * vv[2] + m1.y * vv[3] + m2.x * vv[4] +
-               m2.y * vv[5] + m3.x * vv[6] + m3.y * vv[7];
+    double mm[8];
+    load8(M + (long)r * ldm + cg * 8, mm);
+    double q = mm[0] * vv[0] + mm[1] * vv[1] + mm[2] * vv[2] + mm[3] * vv[3] + mm[4] * vv[4] +
+               mm[5] * vv[5] + mm[6] * vv[6] + mm[7] * vv[7];
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 8);
     q += __shfl_xor(q, 4);
@@ -43,13 +78,14 @@ __device__ __forceinline__ void matvec_128x256(const double *__restrict__ M, lon
 }
 
 // res[c] = sum_r M[r][c] * v[r] for 256 rows x 128 columns, 256 threads
-__device__ __forceinline__ void matvec_t_256x128(const double *__restrict__ M, long ldm,
+template <class T>
+__device__ __forceinline__ void matvec_t_256x128(const T *__restrict__ M, long ldm,
                                                  const double *v, double *res, double *scratch) {
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
   double p0 = 0.0, p1 = 0.0;
   for (int r = half * 128; r < half * 128 + 128; r += 2) {
-    p0 += M[(long)r * ldm + c] * v[r];
-    p1 += M[(long)(r + 1) * ldm + c] * v[r + 1];
+    p0 += (double)M[(long)r * ldm + c] * v[r];
+    p1 += (double)M[(long)(r + 1) * ldm + c] * v[r + 1];
   }
   const double p = p0 + p1;
   if (half == 1) scratch[c] = p;
@@ -61,8 +97,9 @@ __device__ __forceinline__ void matvec_t_256x128(const double *__restrict__ M, l
 // Forward step b (256-blocks): z_b = Dinv_b w_b ; w_i -= L[i,b] z_b  (i > b).
 // Workgroup g handles 128 rows: g = 0,1 the halves of z_b, g >= 2 rows
 // (b+1)*256 + (g-2)*128 ...  Every workgroup recomputes z_b (Dinv_b is L2-resident).
-__global__ __launch_bounds__(256) void trsv_fwd_kernel(const double *__restrict__ L, long ld,
-                                                       const double *__restrict__ Dinv, int b,
+template <class T>
+__global__ __launch_bounds__(256) void trsv_fwd_kernel(const T *__restrict__ L, long ld,
+                                                       const T *__restrict__ Dinv, int b,
                                                        double *__restrict__ w,
                                                        double *__restrict__ z) {
   __shared__ double vb[256], zb[256], upd[128];
@@ -70,7 +107,7 @@ __global__ __launch_bounds__(256) void trsv_fwd_kernel(const double *__restrict_
   const int g = blockIdx.x;
   vb[tid] = w[(long)b * 256 + tid];
   __syncthreads();
-  const double *Db = Dinv + (long)b * 256 * 256;
+  const T *Db = Dinv + (long)b * 256 * 256;
   if (g < 2) {
     matvec_128x256(Db + (long)g * 128 * 256, 256, vb, zb);
     __syncthreads();
@@ -89,8 +126,9 @@ __global__ __launch_bounds__(256) void trsv_fwd_kernel(const double *__restrict_
 // Backward step b: alpha_b = Dinv_b^T w_b ; w_i -= L[b,i]^T alpha_b  (i < b).
 // Workgroup g handles 128 columns: g = 0,1 the halves of alpha_b, g >= 2
 // columns (g-2)*128 ... of the block row b of L.
-__global__ __launch_bounds__(256) void trsv_bwd_kernel(const double *__restrict__ L, long ld,
-                                                       const double *__restrict__ Dinv, int b,
+template <class T>
+__global__ __launch_bounds__(256) void trsv_bwd_kernel(const T *__restrict__ L, long ld,
+                                                       const T *__restrict__ Dinv, int b,
                                                        double *__restrict__ w,
                                                        double *__restrict__ alpha) {
   __shared__ double vb[256], ab[256], upd[128], scratch[128];
@@ -98,7 +136,7 @@ __global__ __launch_bounds__(256) void trsv_bwd_kernel(const double *__restrict_
   const int g = blockIdx.x;
   vb[tid] = w[(long)b * 256 + tid];
   __syncthreads();
-  const double *Db = Dinv + (long)b * 256 * 256;
+  const T *Db = Dinv + (long)b * 256 * 256;
   if (g < 2) {
     matvec_t_256x128(Db + g * 128, 256, vb, ab, scratch);
     if (tid < 128) alpha[(long)b * 256 + g * 128 + tid] = ab[tid];
@@ -114,34 +152,47 @@ __global__ __launch_bounds__(256) void trsv_bwd_kernel(const double *__restrict_
 // nb = number of 256-blocks
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nb, double *w, double *z) {
-  hipLaunchKernelGGL(trsv_fwd_kernel, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
+  hipLaunchKernelGGL(trsv_fwd_kernel<double>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
+                     Dinv, b, w, z);
+}
+void launch_trsv_fwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv,
+                          int b, int nb, double *w, double *z) {
+  hipLaunchKernelGGL(trsv_fwd_kernel<float>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
                      Dinv, b, w, z);
 }
 
 void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nb, double *w, double *alpha) {
   (void)nb;
-  hipLaunchKernelGGL(trsv_bwd_kernel, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+  hipLaunchKernelGGL(trsv_bwd_kernel<double>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+                     alpha);
+}
+void launch_trsv_bwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv,
+                          int b, int nb, double *w, double *alpha) {
+  (void)nb;
+  hipLaunchKernelGGL(trsv_bwd_kernel<float>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
                      alpha);
 }
 
 // alpha = Y z with Y = L^-T upper triangular (row-major): alpha_i = sum_{q >= i0(i)} Y[i][q] z[q],
 // where i0 = first column of row i's 256-block (the block-lower part of Y is never
 // written).  One workgroup per 4 rows (one wave per row), 16-B loads.
-__global__ __launch_bounds__(256) void alpha_from_y_kernel(const double *__restrict__ Y, long ld,
+template <class T>
+__global__ __launch_bounds__(256) void alpha_from_y_kernel(const T *__restrict__ Y, long ld,
                                                            const double *__restrict__ z, long npad,
                                                            double *__restrict__ alpha) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 4 + wid;
   if (i >= npad) return;
   const long q0 = (i / PANEL) * PANEL;
-  const double *row = Y + i * ld;
+  const T *row = Y + i * ld;
   double s0 = 0.0, s1 = 0.0;
   for (long q = q0 + lane * 2; q < npad; q += 128) {
-    const double2 y = *reinterpret_cast<const double2 *>(row + q);
+    double ya, yb;
+    load2(row + q, ya, yb);
     const double2 zz = *reinterpret_cast<const double2 *>(z + q);
-    s0 += y.x * zz.x;
-    s1 += y.y * zz.y;
+    s0 += ya * zz.x;
+    s1 += yb * zz.y;
   }
   double s = s0 + s1;
 #pragma unroll
@@ -152,13 +203,20 @@ __global__ __launch_bounds__(256) void alpha_from_y_kernel(const double *__restr
 void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha) {
   if (npad <= 0) return;
-  hipLaunchKernelGGL(alpha_from_y_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
+  hipLaunchKernelGGL(alpha_from_y_kernel<double>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
+                     (long)ld, z, (long)npad, alpha);
+}
+void launch_alpha_from_y(hipStream_t s, const float *Y, int64_t ld, const double *z,
+                         int64_t npad, double *alpha) {
+  if (npad <= 0) return;
+  hipLaunchKernelGGL(alpha_from_y_kernel<float>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
                      (long)ld, z, (long)npad, alpha);
 }
 
 // scalars[0] = sum_{i<n} 2 log L_ii ; scalars[1] = sum_{i<n} z_i^2 ;
 // scalars[2] = sum_{i<n} y_i alpha_i (only if alpha != nullptr); scalars[3], [4] = min, max L_ii
-__global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restrict__ L, long ld,
+template <class T>
+__global__ __launch_bounds__(1024) void lml_scalars_kernel(const T *__restrict__ L, long ld,
                                                            const double *__restrict__ z,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ alpha,
@@ -166,7 +224,7 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restr
   __shared__ double red[5][16];
   double a = 0.0, b = 0.0, c = 0.0, dmin = INFINITY, dmax = 0.0;
   for (long i = threadIdx.x; i < n; i += 1024) {
-    const double lii = L[i * ld + i];
+    const double lii = (double)L[i * ld + i];
     a += 2.0 * log(lii);
     dmin = fmin(dmin, lii);
     dmax = fmax(dmax, lii);
@@ -210,21 +268,27 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const double *__restr
 
 void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars) {
-  hipLaunchKernelGGL(lml_scalars_kernel, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
+  hipLaunchKernelGGL(lml_scalars_kernel<double>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
+                     (long)n, scalars);
+}
+void launch_lml_scalars(hipStream_t s, const float *L, int64_t ld, const double *z,
+                        const double *y, const double *alpha, int64_t n, double *scalars) {
+  hipLaunchKernelGGL(lml_scalars_kernel<float>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
                      (long)n, scalars);
 }
 
 // one workgroup per row j < m: dot_j = sum_i V[j][i] vec[i], sq_j = sum_i V[j][i]^2
-__global__ __launch_bounds__(256) void rownorm_dot_kernel(const double *__restrict__ V, long ld,
+template <class T>
+__global__ __launch_bounds__(256) void rownorm_dot_kernel(const T *__restrict__ V, long ld,
                                                           const double *__restrict__ vec,
                                                           long ncols, double *__restrict__ dot,
                                                           double *__restrict__ sq) {
   __shared__ double red[2][4];
   const long j = blockIdx.x;
-  const double *row = V + j * ld;
+  const T *row = V + j * ld;
   double a = 0.0, b = 0.0;
   for (long i = threadIdx.x; i < ncols; i += 256) {
-    const double v = row[i];
+    const double v = (double)row[i];
     if (vec) a += v * vec[i];
     b += v * v;
   }
@@ -245,7 +309,13 @@ __global__ __launch_bounds__(256) void rownorm_dot_kernel(const double *__restri
 void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double *vec,
                         int64_t ncols, int64_t m, double *dot, double *sq) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(rownorm_dot_kernel, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
+  hipLaunchKernelGGL(rownorm_dot_kernel<double>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
+                     (long)ncols, dot, sq);
+}
+void launch_rownorm_dot(hipStream_t s, const float *V, int64_t ld, const double *vec,
+                        int64_t ncols, int64_t m, double *dot, double *sq) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(rownorm_dot_kernel<float>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
                      (long)ncols, dot, sq);
 }
 
@@ -253,29 +323,33 @@ void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double
 // >= (r/256 + 1)*256.  This is where the right-hand side R of the triangular
 // inverse lives; the lower triangle + diagonal blocks (the Cholesky work area)
 // are not touched, so the two phases can share the buffer concurrently.
-__global__ __launch_bounds__(256) void zero_upper_kernel(double *__restrict__ R, long ld,
+template <class T>
+__global__ __launch_bounds__(256) void zero_upper_kernel(T *__restrict__ R, long ld,
                                                          long npad) {
   const long row = blockIdx.y;
   const long cstart = (row / PANEL + 1) * PANEL;
   const long c = cstart + ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (c >= npad) return;
-  double2 v;
-  v.x = 0.0;
-  v.y = 0.0;
-  *reinterpret_cast<double2 *>(R + row * ld + c) = v;
+  store2zero(R + row * ld + c);
 }
 
 void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
   if (npad <= PANEL) return;
   dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
-  hipLaunchKernelGGL(zero_upper_kernel, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+  hipLaunchKernelGGL(zero_upper_kernel<double>, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+}
+void launch_zero_upper_blocks(hipStream_t s, float *R, int64_t ld, int64_t npad) {
+  if (npad <= PANEL) return;
+  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
+  hipLaunchKernelGGL(zero_upper_kernel<float>, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
 }
 
 // Y[c0+i][c0+j] = Dinv[j][i]  (256x256 transpose of a diagonal-block inverse into
 // the diagonal block of Y = L^-T)
-__global__ __launch_bounds__(256) void ydiag_kernel(const double *__restrict__ Dinv,
-                                                    double *__restrict__ Y, long ld) {
-  __shared__ double tile[32][33];
+template <class T>
+__global__ __launch_bounds__(256) void ydiag_kernel(const T *__restrict__ Dinv,
+                                                    T *__restrict__ Y, long ld) {
+  __shared__ T tile[32][33];
   const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;  // 8x8 tiles of 32x32
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
@@ -286,24 +360,30 @@ __global__ __launch_bounds__(256) void ydiag_kernel(const double *__restrict__ D
 }
 
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld) {
-  hipLaunchKernelGGL(ydiag_kernel, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
+  hipLaunchKernelGGL(ydiag_kernel<double>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
+}
+void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld) {
+  hipLaunchKernelGGL(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
 }
 
 // zero a rows x cols block (cols a multiple of 2, 16-B aligned)
-__global__ __launch_bounds__(256) void zero_block_kernel(double *__restrict__ B, long ld, long cols) {
+template <class T>
+__global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long ld, long cols) {
   const long r = blockIdx.y;
   const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (c >= cols) return;
-  double2 v;
-  v.x = 0.0;
-  v.y = 0.0;
-  *reinterpret_cast<double2 *>(B + r * ld + c) = v;
+  store2zero(B + r * ld + c);
 }
 
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return;
   dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
-  hipLaunchKernelGGL(zero_block_kernel, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
+  hipLaunchKernelGGL(zero_block_kernel<double>, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
+}
+void launch_zero_block(hipStream_t s, float *B, int64_t ld, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return;
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(zero_block_kernel<float>, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
 }
 
 __global__ void fill_kernel(double *p, long count, double v) {
@@ -319,36 +399,68 @@ void launch_fill(hipStream_t s, double *p, int64_t count, double v) {
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, (long)count, v);
 }
 
-__global__ void extract_lower_kernel(const double *__restrict__ L, long ld, long n,
+template <class T>
+__global__ void extract_lower_kernel(const T *__restrict__ L, long ld, long n,
                                      double *__restrict__ out) {
   const long i = blockIdx.y;
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  out[i * n + j] = (j <= i) ? L[i * ld + j] : 0.0;
+  out[i * n + j] = (j <= i) ? (double)L[i * ld + j] : 0.0;
 }
 
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n, double *out) {
   if (n <= 0) return;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
-  hipLaunchKernelGGL(extract_lower_kernel, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+  hipLaunchKernelGGL(extract_lower_kernel<double>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+}
+void launch_extract_lower(hipStream_t s, const float *L, int64_t ld, int64_t n, double *out) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(extract_lower_kernel<float>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+}
+
+// rows x cols block conversions between the fp32 matrices and the fp64 scratch of the
+// diagonal-block kernel (fp32 path: the diagonal blocks are factored and inverted in fp64)
+template <class S, class D>
+__global__ __launch_bounds__(256) void convert_block_kernel(const S *__restrict__ src, long lds_,
+                                                            D *__restrict__ dst, long ldd, int cols) {
+  const long r = blockIdx.x;
+  for (int c = threadIdx.x; c < cols; c += 256) dst[r * ldd + c] = (D)src[r * lds_ + c];
+}
+void launch_convert_block(hipStream_t s, const float *src, int64_t lds_, double *dst, int64_t ldd,
+                          int rows, int cols) {
+  hipLaunchKernelGGL((convert_block_kernel<float, double>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
+                     dst, (long)ldd, cols);
+}
+void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float *dst, int64_t ldd,
+                          int rows, int cols) {
+  hipLaunchKernelGGL((convert_block_kernel<double, float>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
+                     dst, (long)ldd, cols);
 }
 
 // pack a dense n x n lower factor into the padded buffer (identity padding)
+template <class T>
 __global__ void pack_lower_kernel(const double *__restrict__ in, long n, long npad,
-                                  double *__restrict__ L, long ld) {
+                                  T *__restrict__ L, long ld) {
   const long i = blockIdx.y;
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
   double v = 0.0;
   if (i < n && j < n) v = (j <= i) ? in[i * n + j] : 0.0;
   else if (i == j) v = 1.0;
-  L[i * ld + j] = v;
+  L[i * ld + j] = (T)v;
 }
 
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld) {
   dim3 grid((unsigned)((npad + 255) / 256), (unsigned)npad);
-  hipLaunchKernelGGL(pack_lower_kernel, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
+  hipLaunchKernelGGL(pack_lower_kernel<double>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
+                     (long)ld);
+}
+void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, float *L,
+                       int64_t ld) {
+  dim3 grid((unsigned)((npad + 255) / 256), (unsigned)npad);
+  hipLaunchKernelGGL(pack_lower_kernel<float>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
                      (long)ld);
 }
 

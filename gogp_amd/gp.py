@@ -63,7 +63,7 @@ class GP:
     def __init__(self, NDim: int, Simil: SimilKernel, Noise: Optional[NoiseKernel] = None,
                  ThetaSimil: Optional[Sequence[float]] = None,
                  ThetaNoise: Optional[Sequence[float]] = None,
-                 X=None, Y=None, Parallel: bool = False, device: int = -1):
+                 X=None, Y=None, Parallel: bool = False, device: int = -1, precision: int = 64):
         self.NDim = int(NDim)
         self.Simil = Simil
         self.Noise = Noise
@@ -83,6 +83,12 @@ class GP:
             msg = L.gogp_last_error(None).decode()
             self._h = ctypes.c_void_p()
             raise GogpError(rc, msg)
+        #: 64: fp64 throughout (the reference's arithmetic).  32: the N x N matrices and the
+        #: O(N^3) products in fp32 (BASELINE configs[4]); inputs, kernel evaluation, diagonal
+        #: blocks, vectors and reductions stay fp64 -- include/gogp_hip.h, option "precision"
+        self.precision = int(precision)
+        if self.precision != 64:
+            self._check(L.gogp_set_option(self._h, b"precision", self.precision))
         self._X = np.zeros((0, self.NDim))
         self._Y = np.zeros((0,))
         self._data_dirty = True

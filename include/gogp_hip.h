@@ -294,6 +294,10 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "eager"        1 | 0   Observe also runs the triangular inverse (gradient preparation)
  *                          behind the Cholesky sweep / Gradient computes it lazily  (default 1)
  *   "superpanel"   1..8    256-wide panels per trailing update (K = 256 * value)    (default 2)
+ *   "precision"    64 | 32 fp64 throughout / the N x N matrices and the O(N^3) products in fp32
+ *                          (v_mfma_f32_32x32x2_f32) with fp64 inputs, kernel evaluation, diagonal
+ *                          blocks, vectors and reductions: BASELINE configs[4].  Set it before
+ *                          gogp_set_data (it re-sizes the buffers); single-GPU only.    (default 64)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
  *                          mat.ConditionTolerance                                   (default 16)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */

@@ -523,6 +523,7 @@ def test_anynoise_constant_noise_with_parameter(gpmod):
     x = np.log(np.array(ts + tn))
     lml = g.Observe(x)
     grad = g.Gradient()
+    o.Observe(x)  # the oracle's Gradient consumes dK like the reference's (gp/gp.go:496)
     assert grad[2] == 0.0 and o.Gradient()[2] == 0.0
     x2 = x.copy()
     x2[2] += 1.7
