@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6  # AMD public spec, fp64 matrix = vector
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) = vector
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 ORACLE_FULL_N_LIMIT = 16384
 
@@ -192,6 +193,11 @@ def main():
     steps = args.steps if args.steps is not None else (3 if N > 40000 else 5 if big else 10 if N > 6000 else 50)
     warmup = args.warmup if args.warmup is not None else (1 if big else 2)
     sharded_value = wl.sharded and world > 1  # `value` = the sharded evaluation
+    # configs[4] is an fp32 configuration: single GPU -> the fp32 path (option precision = 32);
+    # the sharded evaluation computes in fp64 (no fp32 tiles yet) and says so in `dtype`
+    prec = 32 if (wl.dtype == "f32" and not sharded_value) else 64
+    dtype = "f32" if prec == 32 else "f64"
+    peak = FP32_PEAK_TFLOPS if prec == 32 else FP64_PEAK_TFLOPS
     X, y = wl.inputs()
     simil, noise = wl.simil, wl.noise
 
@@ -221,7 +227,7 @@ def main():
     out = None
     g = None
     if not sharded_value:
-        g = G.GP(D, simil, noise, device=local_rank)
+        g = G.GP(D, simil, noise, device=local_rank, precision=prec)
         # inputs resident in HBM before anything is timed
         dX = torch.from_numpy(X).to("cuda")
         dy = torch.from_numpy(y).to("cuda")
@@ -286,12 +292,12 @@ def main():
         per_rank = algo_flops_step / (world if sharded_value else 1)
         achieved = (per_rank * steps / (gemm_busy_ms * 1e-3) / 1e12 if gemm_busy_ms > 0 else 0.0)
         try:
-            peak_cal = G.mfma_f64_peak(20000, local_rank)
+            peak_cal = G.mfma_f64_peak(20000, local_rank) if prec == 64 else None
         except Exception:
             peak_cal = None
         out = {
             "metric": "GP.Observe+Gradient evals/sec (%s) at N=%d D=%d" % (
-                "fp64" if wl.dtype == "f64" else "fp32", N, D),
+                "fp64" if dtype == "f64" else "fp32", N, D),
             "value": value,
             "unit": "evals/s",
             "n_gpus": world,
@@ -301,7 +307,7 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": wl.dtype,
+            "dtype": dtype,
             "data": "synthetic",
             "config": {
                 "workload": wl.name + ", Observe+Gradient (hyperparameters-only form), theta perturbed "
@@ -312,12 +318,13 @@ def main():
             "lml": lml,
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gogp::dgemm_nt_kernel (v_mfma_f64_16x16x4_f64 GEMM/SYRK tile kernel)",
+                "kernel": ("gogp::sgemm_nt_kernel (v_mfma_f32_32x32x2_f32 GEMM/SYRK tile kernel)" if prec == 32 else
+                           "gogp::dgemm_nt_kernel (v_mfma_f64_16x16x4_f64 GEMM/SYRK tile kernel)"),
                 "achieved": achieved,
-                "peak": FP64_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / FP64_PEAK_TFLOPS,
-                "frac_wall": (per_rank / (dt / steps) / 1e12) / FP64_PEAK_TFLOPS,
+                "frac": achieved / peak,
+                "frac_wall": (per_rank / (dt / steps) / 1e12) / peak,
                 "traffic": None,
                 "algorithmic_flops_per_step": algo_flops_step,
                 "launches_per_step": gemm_launches / max(1, steps),
@@ -331,8 +338,9 @@ def main():
                         "kernel per step (union of its launch intervals: launches overlap on several "
                         "streams; rocprofv3 --stats sums them, see sum_of_launch_durations_ms_per_step = "
                         "avg_launch_ms x launches_per_step); frac_wall = the same flop / wall time per "
-                        "step (a lower bound that needs no event arithmetic); peak = 78.6 TFLOP/s spec; "
-                        "peak_calibrated = sustained v_mfma_f64 issue-rate microbenchmark on this device",
+                        "step (a lower bound that needs no event arithmetic); peak = 78.6 TFLOP/s fp64 spec "
+                        "(157.3 fp32 matrix); peak_calibrated = sustained v_mfma_f64 issue-rate microbenchmark "
+                        "on this device",
             },
         }
         tr = pmc_traffic(wl.config)
@@ -358,7 +366,7 @@ def main():
             # evaluated at once (gogp_observe_gradient_batch; the reference's optimiser can do the
             # same, optimize.Settings.Concurrent, tutorial/tutorial.go:141) overlap their chains
             k = args.candidates
-            gps = [g] + [G.GP(D, simil, noise, device=local_rank) for _ in range(k - 1)]
+            gps = [g] + [G.GP(D, simil, noise, device=local_rank, precision=prec) for _ in range(k - 1)]
             for gg in gps[1:]:
                 gg.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
             xs = np.array([wl.log_theta(i) for i in range(k)])
@@ -456,7 +464,7 @@ def main():
                 if len(ys) == N and g is not None:
                     g2 = g  # the full workload is already resident
                 else:
-                    g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank)
+                    g2 = G.GP(D, simil, noise, X=Xs, Y=ys, device=local_rank, precision=prec)
                 v = g2.Observe(x)
                 gr = g2.Gradient()
                 mu, sigma = g2.Produce(Z)

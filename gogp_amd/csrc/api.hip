@@ -89,6 +89,11 @@ static void free_n_buffers(gogp_handle *h) {
   (void)hipFree(h->w);
   (void)hipFree(h->alpha);
   (void)hipFree(h->gpart);
+  (void)hipFree(h->rw);
+  (void)hipFree(h->rz);
+  (void)hipFree(h->rd);
+  (void)hipFree(h->rpart);
+  h->rw = h->rz = h->rd = h->rpart = nullptr;
   h->dX = h->dy = h->bufA = h->bufL = h->bufY = h->Dinv = nullptr;
   h->z = h->w = h->alpha = h->gpart = nullptr;
   h->cap_npad = 0;
@@ -269,6 +274,12 @@ static int ensure_n(gogp_handle *h, int64_t n) {
     HIPCHK(h, hipMalloc(&h->w, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->gpart, (size_t)grad_reduce_blocks(npad) * NACC * sizeof(double)));
+    if (h->prec == 32) {  // scratch of the iterative refinement of alpha
+      HIPCHK(h, hipMalloc(&h->rw, (size_t)npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->rz, (size_t)npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->rd, (size_t)npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->rpart, (size_t)REFINE_SLABS * npad * sizeof(double)));
+    }
     h->cap_npad = npad;
     // invalidate the produce workspace that depends on npad
     free_m_buffers(h);
@@ -575,9 +586,32 @@ static int factorize_t(gogp_handle *h, bool eager) {
   }
   order(h, EV_FWD, sz, s);  // z complete
   launch_lml_scalars(s, L, ld, h->z, nullptr, nullptr, h->n, h->scalars);
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  const bool refine = sizeof(T) == 4;
+  if (refine) {
+    // fp32 path: alpha by substitution with the fp32 factor, then `refine_steps` steps of
+    // iterative refinement against the EXACT Gram matrix (recomputed in fp64 on the fly, never
+    // read back from its rounded copy): r = y - K alpha, alpha += K~^-1 r.  The quadratic term of
+    // the LML is y^T alpha of the refined alpha (fp64).  All of it on the chain stream, which is
+    // idle after the last panel; the triangular inverse keeps running on its own streams.
+    if (sz != sp) (void)hipStreamWaitEvent(sp, ev(h, EV_FWD), 0);
+    HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
+    for (int b = npanel - 1; b >= 0; --b) launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->w, h->alpha);
+    const size_t vb = (size_t)npad * sizeof(double);
+    for (int it = 0; it < h->refine_steps; ++it) {
+      launch_residual(sp, h->devP, h->D, h->dX, h->n, npad, h->alpha, h->dy, h->rpart, REFINE_SLABS, h->rw);
+      for (int b = 0; b < npanel; ++b) launch_trsv_fwd_step(sp, L, ld, Dinv, b, npanel, h->rw, h->rz);
+      HIPCHK(h, hipMemcpyAsync(h->rw, h->rz, vb, hipMemcpyDeviceToDevice, sp));
+      for (int b = npanel - 1; b >= 0; --b) launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->rw, h->rd);
+      launch_axpy(sp, h->alpha, h->rd, npad);
+    }
+    launch_dot(sp, h->dy, h->alpha, h->n, h->scalars + 6);
+    order(h, EV_ALPHA, sp, s);
+  }
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
-  if (eager) {
+  if (refine) {
+    if (eager) (void)hipEventRecord(ev(h, EV_TRTRI), st);
+  } else if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
     // triangular inverse is complete (st), instead of 64 dependent substitution steps
     (void)hipStreamWaitEvent(st, ev(h, EV_FWD), 0);
@@ -612,7 +646,8 @@ static int factorize_t(gogp_handle *h, bool eager) {
     return GOGP_ENOTPD;
   }
   // fp32 path: the log-determinant summed from the fp64 diagonal-block factors
-  const double logdet = sizeof(T) == 4 ? h->hscal[5] : h->hscal[0], ztz = h->hscal[1];
+  const double logdet = sizeof(T) == 4 ? h->hscal[5] : h->hscal[0];
+  const double ztz = refine ? h->hscal[6] : h->hscal[1];  // y^T alpha (refined) / z^T z
   // gp/gp.go:244-253
   h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
   h->factored = true;
@@ -1196,6 +1231,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
       h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
       h->trtri_done = h->trtri_pending = h->alpha_pending = false;
     }
+    return GOGP_OK;
+  }
+  if (strcmp(name, "refine_steps") == 0) {
+    if (value < 0 || value > 8) return fail(h, GOGP_EARG, "refine_steps must be 0..8");
+    h->refine_steps = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "cond_limit_log10") == 0) {  // gonum: mat.ConditionTolerance (a package variable), 1e16

@@ -135,6 +135,10 @@ void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevP
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
                   int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT,
                   int64_t ld);
+// r = y - K v with K recomputed in fp64 on the fly (iterative refinement of alpha on the fp32 path);
+// part: nslab * npad doubles of scratch
+void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
+                     const double *v, const double *y, double *part, int nslab, double *r);
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
                   double *prior);
 
@@ -194,6 +198,8 @@ void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const doubl
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
+void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
+void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b
 // helpers of the sharded evaluation (solve.hip)
 void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
                          int n);

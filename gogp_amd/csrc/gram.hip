@@ -125,6 +125,86 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
   }
 }
 
+// Residual of the linear system with the EXACT (fp64, recomputed on the fly) Gram matrix:
+//   part[slab][i] = sum_{j in slab} K_ij v_j     (K_ii includes the noise variance)
+// for the iterative refinement of alpha on the fp32 path: K is never read back from its rounded
+// fp32 copy.  One workgroup = 64 rows x one slab of column tiles; the slabs are summed (fixed
+// order) by kmatvec_finish_kernel, which also forms r = y - K v.
+__global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restrict__ Pp,
+                                                      const double *__restrict__ X, long n,
+                                                      const double *__restrict__ v, long npad,
+                                                      int tiles_per_slab, double *__restrict__ part) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *RiT = sm;             // [D][64] rows of this workgroup, transposed: lane tx reads
+                                // RiT[d*64 + tx] -- consecutive addresses, conflict-free
+  double *CjT = sm + 64 * D;    // [D][64] current column tile (read as broadcasts)
+  double *vj = CjT + 64 * D;    // [64]
+  double *red = vj + 64;        // [4][64]
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+  const long r0 = (long)blockIdx.x * 64;
+  const int slab = blockIdx.y;
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int r = idx / D, d = idx - r * D;
+    RiT[d * 64 + r] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
+  }
+  // thread (tx, ty): row r0 + tx, columns ty*16 .. ty*16+15 of every tile
+  double acc = 0.0;
+  const long gi = r0 + tx;
+  const int ntile = (int)(npad / 64);
+  for (int t = slab * tiles_per_slab; t < (slab + 1) * tiles_per_slab && t < ntile; ++t) {
+    const long c0 = (long)t * 64;
+    __syncthreads();
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int r = idx / D, d = idx - r * D;
+      CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+    }
+    if (tid < 64) vj[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
+    __syncthreads();
+    if (gi < n) {
+      const double *ri = RiT + tx;
+      for (int cc = 0; cc < 16; ++cc) {
+        const int c = ty * 16 + cc;
+        const long gj = c0 + c;
+        if (gj < n) {
+          const double *cj = CjT + c;
+          double k = simil_value(
+              P, [&](int d) { return ri[d * 64]; }, [&](int d) { return cj[d * 64]; });
+          if (gi == gj) k += P.noise_var;
+          acc += k * vj[c];
+        }
+      }
+    }
+  }
+  red[ty * 64 + tx] = acc;
+  __syncthreads();
+  if (ty == 0 && gi < npad)
+    part[(long)slab * npad + gi] = red[tx] + red[64 + tx] + red[128 + tx] + red[192 + tx];
+}
+
+// r_i = y_i - sum_slab part[slab][i]  (i < n; 0 beyond)
+__global__ void kmatvec_finish_kernel(const double *__restrict__ part, int nslab, long npad, long n,
+                                      const double *__restrict__ y, double *__restrict__ r) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  double s = 0.0;
+  for (int q = 0; q < nslab; ++q) s += part[(long)q * npad + i];
+  r[i] = (i < n) ? y[i] - s : 0.0;
+}
+
+void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                     int64_t npad, const double *v, const double *y, double *part, int nslab, double *r) {
+  const int ntile = (int)(npad / 64);
+  const int tps = (ntile + nslab - 1) / nslab;
+  const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
+  hipLaunchKernelGGL(kmatvec_kernel, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n, v,
+                     (long)npad, tps, part);
+  hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
+                     (long)npad, (long)n, y, r);
+}
+
 __global__ void prior_kernel(const DevParams *__restrict__ Pp, const double *__restrict__ Z,
                              long m, double *__restrict__ prior) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;

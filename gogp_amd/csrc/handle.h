@@ -13,6 +13,8 @@ struct Dist2D;  // dist2d.hip
 using gogp::DevParams;
 using gogp::GemmProfile;
 
+constexpr int REFINE_SLABS = 8;  // column slabs of the residual kernel (gram.hip: launch_residual)
+
 struct gogp_handle {
   gogp_desc desc;
   int device = 0;
@@ -28,6 +30,8 @@ struct gogp_handle {
   double *dscr = nullptr;     // fp32 path: fp64 scratch of the diagonal-block kernel (3 x 256 x 256)
   int prec = 64;              // 64: fp64 throughout; 32: N x N matrices and O(N^3) products in fp32
   size_t esz() const { return prec == 32 ? sizeof(float) : sizeof(double); }
+  int refine_steps = 1;       // fp32 path: iterative-refinement steps of alpha against the fp64 K
+  double *rw = nullptr, *rz = nullptr, *rd = nullptr, *rpart = nullptr;  // its scratch
   long long *info = nullptr;
   double *gpart = nullptr, *gout = nullptr;
   DevParams *devP = nullptr;

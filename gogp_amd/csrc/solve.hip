@@ -392,6 +392,34 @@ __global__ void fill_kernel(double *p, long count, double v) {
     p[i] = v;
 }
 
+__global__ void axpy_kernel(double *__restrict__ a, const double *__restrict__ b, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) a[i] += b[i];
+}
+void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (long)count);
+}
+
+// out[0] = sum_{i<n} a_i b_i  (single workgroup, fixed order)
+__global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                   long n, double *__restrict__ out) {
+  __shared__ double red[16];
+  double v = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) v += a[i] * b[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
+  }
+}
+void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out) {
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, a, b, (long)n, out);
+}
+
 void launch_fill(hipStream_t s, double *p, int64_t count, double v) {
   if (count <= 0) return;
   int blocks = (int)((count + 255) / 256);

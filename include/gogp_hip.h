@@ -298,6 +298,8 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          (v_mfma_f32_32x32x2_f32) with fp64 inputs, kernel evaluation, diagonal
  *                          blocks, vectors and reductions: BASELINE configs[4].  Set it before
  *                          gogp_set_data (it re-sizes the buffers); single-GPU only.    (default 64)
+ *   "refine_steps" 0..8    precision 32 only: steps of iterative refinement of alpha against
+ *                          the exact (fp64, recomputed) Gram matrix                    (default 1)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
  *                          mat.ConditionTolerance                                   (default 16)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */

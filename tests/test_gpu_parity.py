@@ -591,6 +591,61 @@ def test_condition_error_like_gonum(gpmod):
     assert g.LML() == lml_ref
 
 
+@pytest.mark.parametrize("shape", ["config5", "config3"])
+def test_fp32_path_accuracy_contract(gpmod, shape):
+    """BASELINE configs[4] is an fp32 configuration.  The fp32 path (option precision = 32) keeps
+    the N x N matrices and the O(N^3) products in fp32 (v_mfma_f32_32x32x2_f32) and everything
+    else -- inputs, kernel evaluation, 256x256 diagonal blocks, log-determinant, substitutions,
+    one step of iterative refinement of alpha against the exact Gram matrix, gradient sums --
+    in fp64.  Contract against the fp64 oracle (DESIGN.md "fp32 path"; measured values are
+    5-20x below these bounds):
+        config-5 shape (ARD-RBF, D=32):  LML 2e-6 rel, gradient 2e-5 of max|g|, alpha 2e-5,
+                                         mu 1e-3, sigma 1e-4
+        config-3 shape (RBF, D=8, cond(K) 10x larger): LML 1e-5, gradient 1e-4"""
+    from gogp_amd import configs
+    from oracle.oracle import FastOracle
+    n = 4096
+    wl = configs.workload(5 if shape == "config5" else 3, n)
+    X, y = wl.inputs()
+    Z = wl.test_points(64)
+    x = wl.log_theta(0)
+    o = FastOracle(wl.D, wl.simil, wl.noise)
+    o.set_data(X, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    mu_o, sg_o = o.Produce(Z)
+    g = gpmod.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, precision=32)
+    lml, grad = g.Observe(x), g.Gradient()
+    mu, sg = g.Produce(Z)
+    tol_lml, tol_grad = (2e-6, 2e-5) if shape == "config5" else (1e-5, 1e-4)
+    assert abs(lml - lml_o) <= tol_lml * abs(lml_o), (lml, lml_o)
+    assert np.abs(grad - grad_o).max() <= tol_grad * np.abs(grad_o).max(), (grad, grad_o)
+    assert np.abs(g.Alpha - o.Alpha).max() <= 2e-5 * np.abs(o.Alpha).max()
+    assert np.abs(mu - mu_o).max() <= 1e-3 * np.abs(mu_o).max()
+    assert np.abs(sg - sg_o).max() <= 2e-4 * np.abs(sg_o).max()
+    # the factor is exported in fp64 whatever the storage type: L L^T = K to fp32 accuracy
+    rows = np.array([0, 17, n - 1])
+    Lr = g.L_rows(rows)
+    th = np.exp(x)
+    for a, i in enumerate(rows):
+        kii = th[0] + th[-1] ** 2
+        assert abs(float(Lr[a] @ Lr[a]) - kii) <= 1e-5 * kii
+    d = g.L_diag()
+    assert d.shape == (n,) and np.all(d > 0)
+    # second evaluation on the same handle, then Absorb (lazy path) agree with the first
+    assert abs(g.Observe(x) - lml) <= 1e-12 * abs(lml)
+    g.ThetaSimil, g.ThetaNoise = list(th[:-1]), [float(th[-1])]
+    g.Absorb(X, y)
+    assert abs(g.LML() - lml) <= 1e-9 * abs(lml)
+    # what the fp32 path does not offer fails loudly
+    xf = np.concatenate([x, X[:8].reshape(-1), y[:8]])
+    g8 = gpmod.GP(wl.D, wl.simil, wl.noise, precision=32)
+    g8.Observe(xf)
+    with pytest.raises(gpmod.GogpError):
+        g8.Gradient()  # full Observe form: fp64 only
+    g.close()
+    g8.close()
+
+
 def test_observe_gradient_batch_matches_single_calls(gpmod):
     """k candidates evaluated at once (one host thread per handle) give bit for bit what the
     same handles return one at a time."""
