@@ -233,6 +233,30 @@ def test_full_form_gradient_vs_faithful_oracle(gpmod, name, D, simil, noise, ts,
     np.testing.assert_array_equal(g.Y, y)
 
 
+@pytest.mark.parametrize("D", [40, 64])
+def test_full_form_gradient_at_max_ndim(gpmod, D):
+    """NDim up to GOGP_MAX_NDIM = 64: the input-gradient kernel needs 99 KB of dynamic LDS at
+    D = 64 (above the 64 KB default limit, raised explicitly); hyperparameters-only and full
+    forms with an ARD kernel against the faithful oracle."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(D)
+    n = 70
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise
+    th = np.concatenate([[1.1], np.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D)), [0.2]])
+    x = np.concatenate([np.log(th), X.reshape(-1), y])
+    g = gpmod.GP(D, simil, noise)
+    o = Oracle(D, simil, noise)
+    lml, lml_o = g.Observe(x), o.Observe(x)
+    assert abs(lml - lml_o) <= 1e-8 * max(1.0, abs(lml_o))
+    grad, grad_o = g.Gradient(), o.Gradient()
+    assert grad.shape == grad_o.shape == x.shape
+    assert np.abs(grad - grad_o).max() <= 1e-6 * max(1.0, np.abs(grad_o).max())
+    g2 = gpmod.GP(D, simil, noise, X=X, Y=y)
+    assert abs(g2.Observe(np.log(th)) - lml_o) <= 1e-8 * max(1.0, abs(lml_o))
+    np.testing.assert_allclose(g2.Gradient(), grad_o[:D + 2], rtol=1e-6, atol=1e-8)
+
+
 def test_full_form_gradient_mid_size(gpmod):
     """Input/output gradient at a size that spans several 64-row tiles and 256-panels,
     against central differences of the HIP LML itself on a few coordinates."""
