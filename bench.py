@@ -344,7 +344,7 @@ def main():
             },
         }
         tr = pmc_traffic(wl.config)
-        if tr is not None:
+        if tr is not None and tr.get("N") == N and not sharded_value:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_note"] = tr.get("note")
         if gram_n and grad_n:

@@ -56,6 +56,13 @@ using namespace gogp;
 
 namespace gogp {
 
+// The triangular inverse runs INV_LAG block columns behind the Cholesky sweep in the enqueue
+// order (so that the Cholesky chain never queues behind an exchange of the inverse on the
+// single, in-order communication stream); the L panel buffers therefore live INV_LAG steps
+// longer: a ring of LRING = INV_LAG + 2.
+constexpr int INV_LAG = 2;
+constexpr int LRING = INV_LAG + 2;
+
 struct Dist2D {
   int rank = 0, nranks = 1, Pr = 1, Pc = 1, pr = 0, pc = 0;
   int nb = 512, tpb = 4, tpb_shift = 2, nb_shift = 9;
@@ -63,7 +70,7 @@ struct Dist2D {
   Transport *tr = nullptr;
   hipStream_t sc = nullptr;
   double *A = nullptr, *Lch = nullptr, *Ych = nullptr, *Dinv = nullptr;
-  double *Lrow[2] = {nullptr, nullptr}, *Lcol[2] = {nullptr, nullptr};
+  double *Lrow[LRING] = {nullptr, nullptr, nullptr, nullptr}, *Lcol[LRING] = {nullptr, nullptr, nullptr, nullptr};
   double *Yrow[2] = {nullptr, nullptr}, *Ycol[2] = {nullptr, nullptr};
   double *pack = nullptr;   // send staging of the strided column pieces
   double *scr = nullptr;    // 2 x 256 x 256 scratch of the diagonal tile
@@ -100,12 +107,16 @@ static inline void rec(gogp_handle *h, size_t i, hipStream_t s) { (void)hipEvent
 static inline void wait(gogp_handle *h, hipStream_t s, size_t i) { (void)hipStreamWaitEvent(s, ev(h, i), 0); }
 
 static void dist_free_n(Dist2D *d) {
-  for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Lrow[0], d->Lrow[1], d->Lcol[0], d->Lcol[1],
-                    d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack, d->yloc, d->red, d->ared,
-                    d->gpart})
+  for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack,
+                    d->yloc, d->red, d->ared, d->gpart})
     (void)hipFree(p);
+  for (int i = 0; i < LRING; ++i) {
+    (void)hipFree(d->Lrow[i]);
+    (void)hipFree(d->Lcol[i]);
+    d->Lrow[i] = d->Lcol[i] = nullptr;
+  }
   d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = nullptr;
-  for (int i = 0; i < 2; ++i) d->Lrow[i] = d->Lcol[i] = d->Yrow[i] = d->Ycol[i] = nullptr;
+  for (int i = 0; i < 2; ++i) d->Yrow[i] = d->Ycol[i] = nullptr;
   d->cap_npad = 0;
   d->bytes = 0;
 }
@@ -240,10 +251,12 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
     DMALLOC(d->Lch, mrows * ncols);
     DMALLOC(d->Ych, mrows * ncols);
     DMALLOC(d->Dinv, (size_t)d->NB * nb2);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LRING; ++i) {
       DMALLOC(d->Lrow[i], mrows * d->nb);
-      DMALLOC(d->Yrow[i], mrows * d->nb);
       DMALLOC(d->Lcol[i], ncols * d->nb);
+    }
+    for (int i = 0; i < 2; ++i) {
+      DMALLOC(d->Yrow[i], mrows * d->nb);
       DMALLOC(d->Ycol[i], ncols * d->nb);
     }
     DMALLOC(d->pack, (size_t)(d->Pc / d->Pr) * ncols * d->nb);
@@ -334,13 +347,14 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
   for (hipStream_t qs : {sp, st, s2, sc}) wait(h, qs, EV_GRAM);
 
   std::vector<XferOp> ops;
-  for (int P = 0; P < NB; ++P) {
+  // ---- Cholesky part of block column P (sections 1-4) --------------------------------------------
+  auto chol_step = [&](int P) -> int {
     const int kr = P % Pr, kc = P % Pc;
     const int bi_d = P / Pr, bj_d = P / Pc;
     const int bi0 = first_gt(P, pr, Pr);  // local row blocks [0, bi0): global <= P; [bi0, mloc): > P
     const int bj0 = first_gt(P, pc, Pc);
     const bool in_col = (pc == kc), in_row = (pr == kr), is_diag = in_col && in_row;
-    const int slot = P & 1;
+    const int lslot = P % LRING;
     const int diag_rank = d->rank_of(kr, kc);
     double *Dv = d->Dinv + (size_t)P * nb2;
     const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);  // I hold tiles of block column P+1
@@ -376,10 +390,10 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     }
 
     // ---- 3. exchange of the L panel -----------------------------------------------------------
-    double *Lrow = in_col ? d->lchunk(bj_d) : d->Lrow[slot];
-    double *Lcol = d->Lcol[slot];
-    if (P >= 2)  // the panel buffers of step P-2 are still being read by its updates
-      for (int k : {EUPD, ELA, ERUPD, ERLA}) wait(h, sc, E(P - 2, k));
+    double *Lrow = in_col ? d->lchunk(bj_d) : d->Lrow[lslot];
+    double *Lcol = d->Lcol[lslot];
+    if (P >= LRING)  // the panel buffers of step P - LRING are still being read by its updates
+      for (int k : {EUPD, ELA, ERUPD, ERLA}) wait(h, sc, E(P - LRING, k));
     ops.clear();
     const int64_t cnt_row = (int64_t)(mloc - bi0) * (int64_t)nb2;
     if (in_col) {
@@ -440,6 +454,21 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
       }
       rec(h, E(P, EUPD), s);
     }
+    return GOGP_OK;
+  };
+
+  // ---- inverse part of block column P (sections 5-7) ------------------------------------------------
+  auto inv_step = [&](int P) -> int {
+    const int kr = P % Pr, kc = P % Pc;
+    const int bi_d = P / Pr, bj_d = P / Pc;
+    const int bi0 = first_gt(P, pr, Pr);
+    const int bj0 = first_gt(P, pc, Pc);
+    const bool in_col = (pc == kc), in_row = (pr == kr), is_diag = in_col && in_row;
+    const int slot = P & 1, lslot = P % LRING;
+    double *Dv = d->Dinv + (size_t)P * nb2;
+    const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);
+    const int src_r = pc % Pr;
+    double *Lcol = d->Lcol[lslot];
 
     // ---- 5. column panel P of Y = L^-T -----------------------------------------------------------
     const int bim = in_row ? bi0 - 1 : bi0;  // local row blocks with global index < P
@@ -459,6 +488,8 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     // ---- 6. exchange of the Y panel ------------------------------------------------------------
     double *Yrow = in_col ? d->ychunk(bj_d) : d->Yrow[slot];
     double *Ycol = d->Ycol[slot];
+    if (P >= 2)  // the Y panel buffers of step P-2 are still being read by its updates
+      for (int k : {ERUPD, ERLA}) wait(h, sc, E(P - 2, k));
     ops.clear();
     const int64_t cnt_yrow = (int64_t)bi0 * (int64_t)nb2;
     if (in_col) {
@@ -516,6 +547,18 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
                         &gk);
       }
       rec(h, E(P, ERUPD), s2);
+    }
+    return GOGP_OK;
+  };
+
+  for (int t = 0; t < NB + INV_LAG; ++t) {
+    if (t < NB) {
+      rc = chol_step(t);
+      if (rc != GOGP_OK) return rc;
+    }
+    if (t >= INV_LAG) {
+      rc = inv_step(t - INV_LAG);
+      if (rc != GOGP_OK) return rc;
     }
   }
 

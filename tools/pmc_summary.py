@@ -5,10 +5,13 @@ import re
 
 
 def short(n):
-    m = re.search(r'dgemm_nt_kernel<(\d), (\d+), (\d), (true|false)>', n)
-    if m:  # MODE, TILE, WAVES (the staging flavour is not distinguished)
+    m = re.search(r'dgemm_nt_kernel<(\d), (\d+), (\d)>', n)
+    if m:  # MODE, TILE, WAVES
         return 'dgemm_nt_kernel<%s, %s, %s>' % m.group(1, 2, 3)
-    for k in ['diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y', 'zero_upper',
+    m = re.search(r'sgemm_nt_kernel<(\d), (\d+)>', n)
+    if m:
+        return 'sgemm_nt_kernel<%s, %s>' % m.group(1, 2)
+    for k in ['diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y', 'zero_upper', 'kmatvec', 'convert_block',
               'mfma_f64_peak']:
         if k in n:
             return k

@@ -1,0 +1,23 @@
+"""HBM-side bytes per launch of the dominant kernel family from the separate rocprofv3 --pmc passes
+(FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of
+a wide coalesced read, so it is doubled -- MI355X_MICROARCH.md, section HBM).
+usage: pmc_traffic.py <config> <fetch_dir> <write_dir> <family-substring>  -> one JSON object on stdout"""
+import collections, csv, glob, json, sys
+cfg, fdir, wdir, fam = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+def load(path, counter):
+    f = glob.glob(path + "/*/*_counter_collection.csv")[0]
+    tot, disp = 0.0, set()
+    for r in csv.DictReader(open(f)):
+        if fam in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            tot += float(r['Counter_Value'])
+            disp.add(r['Dispatch_Id'])
+    return tot, len(disp)
+fetch, nf = load(fdir, 'FETCH_SIZE')
+write, nw = load(wdir, 'WRITE_SIZE')
+bytes_total = (2.0 * fetch + write) * 1024.0
+print(json.dumps({cfg: {
+    "bytes_per_launch": bytes_total / max(1, nf),
+    "launches_counted": nf,
+    "fetch_bytes_corrected": 2.0 * fetch * 1024.0, "write_bytes": write * 1024.0,
+    "note": "sum over all launches of %s in the profiled run of (2 x FETCH_SIZE + WRITE_SIZE) KiB / number "
+            "of launches; separate --pmc passes of `bench.py --steps 2 --warmup 1` (3 evaluations)" % fam}}))

@@ -1,0 +1,31 @@
+set -e
+# Round-2 profiles.  The JSON lines come from the default commands; the rocprofv3 passes skip the
+# CPU baseline and the secondary measurements so that their per-kernel sums are per
+# Observe+Gradient evaluation.  PMC passes are separate runs (no trace domains besides kernel-trace).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r2
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+FAST="--no-cpu-baseline --no-produce --candidates 1"
+python3 $R/bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+echo "bench c3 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --steps 5 --warmup 1 $FAST > $O/stats_c3.log 2>&1
+echo "stats c3 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config 2 --steps 20 --warmup 2 $FAST > $O/stats_c2.log 2>&1
+echo "stats c2 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config 5 --nobs 32768 --steps 2 --warmup 1 $FAST > $O/stats_c5.log 2>&1
+echo "stats c5 (N=32768) done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_c3 -- python3 $R/bench.py --steps 2 --warmup 1 $FAST > $O/pmc_sq_c3.log 2>&1
+echo "pmc sq c3 done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c3 -- python3 $R/bench.py --steps 2 --warmup 1 $FAST > $O/pmc_fetch_c3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_write_c3 -- python3 $R/bench.py --steps 2 --warmup 1 $FAST > $O/pmc_write_c3.log 2>&1
+echo "pmc traffic c3 done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_c5 -- python3 $R/bench.py --config 5 --nobs 16384 --steps 2 --warmup 1 $FAST > $O/pmc_sq_c5.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c5 -- python3 $R/bench.py --config 5 --nobs 16384 --steps 2 --warmup 1 $FAST > $O/pmc_fetch_c5.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_write_c5 -- python3 $R/bench.py --config 5 --nobs 16384 --steps 2 --warmup 1 $FAST > $O/pmc_write_c5.log 2>&1
+echo "pmc c5 (N=16384) done"
+cd $R
+python3 tools/pmc_summary.py $O/pmc_sq_c3 $O/pmc_fetch_c3 $O/pmc_write_c3 > $O/pmc_summary_c3.txt
+python3 tools/pmc_summary.py $O/pmc_sq_c5 $O/pmc_fetch_c5 $O/pmc_write_c5 > $O/pmc_summary_c5.txt
+find $O -name "*counter_collection.csv" -size +6M -delete
+find $O -name "*kernel_trace.csv" -size +6M -delete
+ls -la $O
