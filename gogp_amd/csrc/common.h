@@ -205,8 +205,9 @@ void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double 
                          int n);
 void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
                         int first, int stride);
+int64_t chunk_tdot_scratch(int64_t max_rows, int nb);  // doubles of `part` scratch
 void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
-                       double *out);
+                       double *part, double *out);
 void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
                         const double *z, double *out);
 void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,

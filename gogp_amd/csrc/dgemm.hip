@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 
   // ---- tile assignment ----------------------------------------------------
   int t = blockIdx.x;
-  if (MODE != GEMM_LAUUM) {
+  if (MODE != GEMM_LAUUM && !(MODE == GEMM_RECT && g.rule)) {
     // XCD-aware remap (blocks b and b+8 share an XCD/L2): give each XCD a
     // contiguous chunk of the tile list; bijective for any grid size.
     const int nwg = gridDim.x;
@@ -104,7 +104,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
   }
   int ti, tj;
-  if (MODE == GEMM_RECT) {
+  if (MODE == GEMM_RECT && g.rule) {
+    // Filtered launch of the sharded path: the kept tiles form a staircase (global lower
+    // triangle), so contiguous chunks per XCD would be badly unbalanced.  Deal the tile ROWS
+    // cyclically instead: the XCD group b & 7 takes rows x, x + 8, ... (a row's tiles share the
+    // A panel in that XCD's L2).  The grid is 8 * ceil(mt / 8) * nt workgroups.
+    const int x = t & 7, slot = t >> 3;
+    const int rr = slot / g.nt;
+    ti = x + 8 * rr;
+    tj = slot - rr * g.nt;
+    if (ti >= g.mt) return;
+  } else if (MODE == GEMM_RECT) {
     ti = t / g.nt;
     tj = t - ti * g.nt;
     if (g.trap && (tj * BT) / PANEL > (ti * BT) / PANEL) return;  // whole-workgroup exit
@@ -328,13 +338,14 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     g.mt = mt * 2;
     g.nt = nt * 2;
     g.tpb_shift += 1;  // distribution blocks counted in 64-wide tiles
-    const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
+    const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
+                                        : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(dim3(n64), dim3(256), dgemm_nt_kernel<GEMM_RECT, 64, 4>);
     else
       GOGP_LAUNCH(dim3(n64), dim3(256), dgemm_nt_kernel<GEMM_LOWER, 64, 4>);
   } else if (mode == GEMM_LAUUM || ntiles >= 3072) {
-    const dim3 grid(ntiles), block8(512);
+    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block8(512);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_RECT, 128, 8>);
     else if (mode == GEMM_LOWER)
@@ -342,7 +353,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     else
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_LAUUM, 128, 8>);
   } else {
-    const dim3 grid(ntiles), block(256);
+    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block(256);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block, dgemm_nt_kernel<GEMM_RECT, 128, 4>);
     else

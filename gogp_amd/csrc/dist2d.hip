@@ -78,6 +78,7 @@ struct Dist2D {
   double *red = nullptr;    // [z (npad) | logdet | failing pivot + 1 of every rank]
   double *ared = nullptr;   // alpha partial sums (npad)
   double *gpart = nullptr;
+  double *tpart = nullptr;  // scratch of the z partial sums (chunk_tdot)
   int64_t cap_npad = 0;
   int64_t bytes = 0;
   int ldA() const { return nloc * nb; }
@@ -108,14 +109,14 @@ static inline void wait(gogp_handle *h, hipStream_t s, size_t i) { (void)hipStre
 
 static void dist_free_n(Dist2D *d) {
   for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack,
-                    d->yloc, d->red, d->ared, d->gpart})
+                    d->yloc, d->red, d->ared, d->gpart, d->tpart})
     (void)hipFree(p);
   for (int i = 0; i < LRING; ++i) {
     (void)hipFree(d->Lrow[i]);
     (void)hipFree(d->Lcol[i]);
     d->Lrow[i] = d->Lcol[i] = nullptr;
   }
-  d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = nullptr;
+  d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = d->tpart = nullptr;
   for (int i = 0; i < 2; ++i) d->Yrow[i] = d->Ycol[i] = nullptr;
   d->cap_npad = 0;
   d->bytes = 0;
@@ -264,6 +265,7 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
     DMALLOC(d->red, (size_t)npad + 1 + d->nranks);
     DMALLOC(d->ared, (size_t)npad);
     DMALLOC(d->gpart, (size_t)grad_reduce_blocks_local((int64_t)mrows, (int64_t)ncols) * NACC);
+    DMALLOC(d->tpart, (size_t)chunk_tdot_scratch((int64_t)mrows, d->nb));
     d->cap_npad = npad;
   }
   return GOGP_OK;
@@ -391,7 +393,9 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
 
     // ---- 3. exchange of the L panel -----------------------------------------------------------
     double *Lrow = in_col ? d->lchunk(bj_d) : d->Lrow[lslot];
-    double *Lcol = d->Lcol[lslot];
+    // square grid, diagonal rank: my tile columns are my tile rows -- no copy, the same buffer
+    const bool alias = (q == 1 && pc % Pr == pr);
+    double *Lcol = alias ? Lrow : d->Lcol[lslot];
     if (P >= LRING)  // the panel buffers of step P - LRING are still being read by its updates
       for (int k : {EUPD, ELA, ERUPD, ERLA}) wait(h, sc, E(P - LRING, k));
     ops.clear();
@@ -418,7 +422,7 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     if (src_r != pr && nloc - bj0 > 0)
       ops.push_back({d->rank_of(src_r, kc), false, Lcol + (size_t)bj0 * nb2, (int64_t)(nloc - bj0) * (int64_t)nb2});
     TRCHK(d->tr->group(sc, ops, &e_));
-    if (src_r == pr)
+    if (src_r == pr && !alias)
       launch_pack_blocks(sc, Lcol + (size_t)bj0 * nb2, Lrow, nloc - bj0, (int64_t)nb2,
                          bj0 * q + (pc - pr) / Pr, q);
     rec(h, E(P, EL), sc);
@@ -468,7 +472,8 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     double *Dv = d->Dinv + (size_t)P * nb2;
     const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);
     const int src_r = pc % Pr;
-    double *Lcol = d->Lcol[lslot];
+    const bool alias = (q == 1 && src_r == pr);
+    double *Lcol = alias ? (in_col ? d->lchunk(bj_d) : d->Lrow[lslot]) : d->Lcol[lslot];
 
     // ---- 5. column panel P of Y = L^-T -----------------------------------------------------------
     const int bim = in_row ? bi0 - 1 : bi0;  // local row blocks with global index < P
@@ -480,14 +485,14 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
                         d->ychunk(bj_d), nb, pf);
       if (is_diag) launch_transpose_sq(st, Dv, nb, d->ychunk(bj_d) + (size_t)bi_d * nb2, nb, nb);
       if (bi0 > 0)  // z_P += sum_I Y[I, P]^T y_I over my tile rows
-        launch_chunk_tdot(st, d->ychunk(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->red + (size_t)P * nb);
+        launch_chunk_tdot(st, d->ychunk(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->tpart, d->red + (size_t)P * nb);
       rec(h, E(P, EYCH), st);
       wait(h, sc, E(P, EYCH));
     }
 
     // ---- 6. exchange of the Y panel ------------------------------------------------------------
     double *Yrow = in_col ? d->ychunk(bj_d) : d->Yrow[slot];
-    double *Ycol = d->Ycol[slot];
+    double *Ycol = alias ? Yrow : d->Ycol[slot];
     if (P >= 2)  // the Y panel buffers of step P-2 are still being read by its updates
       for (int k : {ERUPD, ERLA}) wait(h, sc, E(P - 2, k));
     ops.clear();
@@ -512,7 +517,7 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     if (src_r != pr && bj0 > 0)
       ops.push_back({d->rank_of(src_r, kc), false, Ycol, (int64_t)bj0 * (int64_t)nb2});
     TRCHK(d->tr->group(sc, ops, &e_));
-    if (src_r == pr) launch_pack_blocks(sc, Ycol, Yrow, bj0, (int64_t)nb2, (pc - pr) / Pr, q);
+    if (src_r == pr && !alias) launch_pack_blocks(sc, Ycol, Yrow, bj0, (int64_t)nb2, (pc - pr) / Pr, q);
     rec(h, E(P, EY), sc);
 
     // ---- 7. R update (rows <= P, columns > P) and the rank-nb update of K^-1 -----------------------

@@ -68,14 +68,20 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int t = blockIdx.x;
-  if (MODE != GEMM_LAUUM) {  // XCD-aware remap, bijective for any grid size (dgemm.hip)
+  if (MODE != GEMM_LAUUM && !(MODE == GEMM_RECT && g.rule)) {  // XCD-aware remap (dgemm.hip)
     const int nwg = gridDim.x;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = t & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
   }
   int ti, tj;
-  if (MODE == GEMM_RECT) {
+  if (MODE == GEMM_RECT && g.rule) {  // filtered launch: tile rows dealt cyclically to the XCDs (dgemm.hip)
+    const int x = t & 7, slot = t >> 3;
+    const int rr = slot / g.nt;
+    ti = x + 8 * rr;
+    tj = slot - rr * g.nt;
+    if (ti >= g.mt) return;
+  } else if (MODE == GEMM_RECT) {
     ti = t / g.nt;
     tj = t - ti * g.nt;
     if (g.trap && (tj * BT) / PANEL > (ti * BT) / PANEL) return;
@@ -284,13 +290,14 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
     g.mt = mt * 2;
     g.nt = nt * 2;
     g.tpb_shift += 1;
-    const int n64 = (mode == GEMM_RECT) ? g.mt * g.nt : g.mt * (g.mt + 1) / 2;
+    const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
+                                        : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_RECT, 64>);
     else
       GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_LOWER, 64>);
   } else {
-    const dim3 gridd(ntiles), block(256);
+    const dim3 gridd(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block(256);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_RECT, 128>);
     else if (mode == GEMM_LOWER)

@@ -535,8 +535,17 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(double *__restrict__ d
   const long d = blockIdx.y;
   const double2 *sp = reinterpret_cast<const double2 *>(src + (long)(first + d * stride) * blk);
   double2 *dp = reinterpret_cast<double2 *>(dst + d * blk);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < blk / 2; i += (long)gridDim.x * 256)
-    dp[i] = sp[i];
+  const long n2 = blk / 2, step = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  // four 16-B loads in flight per thread before the stores
+  for (; i + 3 * step < n2; i += 4 * step) {
+    const double2 a = sp[i], b = sp[i + step], c = sp[i + 2 * step], e = sp[i + 3 * step];
+    dp[i] = a;
+    dp[i + step] = b;
+    dp[i + 2 * step] = c;
+    dp[i + 3 * step] = e;
+  }
+  for (; i < n2; i += step) dp[i] = sp[i];
 }
 
 void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
@@ -546,24 +555,45 @@ void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk,
                      (long)blk, first, stride);
 }
 
-// out[c] = sum_{r < rows} chunk[r][c] * v[r]   (chunk rows x nb, leading dimension nb)
-// one workgroup per 64 columns; 4 waves split the rows; fixed-order reduction
+// out[c] = sum_{r < rows} chunk[r][c] * v[r]   (chunk rows x nb, leading dimension nb).
+// Two stages, fixed summation order: workgroup (column group of 64, row slab of TDOT_SLAB rows)
+// writes part[slab][c]; the finish kernel adds the slabs.  part: (rows/TDOT_SLAB + 1) * nb doubles.
+constexpr int TDOT_SLAB = 256;
 __global__ __launch_bounds__(256) void chunk_tdot_kernel(const double *__restrict__ chunk, long rows,
                                                          int nb, const double *__restrict__ v,
-                                                         double *__restrict__ out) {
+                                                         double *__restrict__ part) {
   __shared__ double red[4][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  double a = 0.0;
-  for (long r = wid; r < rows; r += 4) a += chunk[r * nb + c] * v[r];
-  red[wid][lane] = a;
+  const long r0 = (long)blockIdx.y * TDOT_SLAB;
+  const long r1 = (r0 + TDOT_SLAB < rows) ? r0 + TDOT_SLAB : rows;
+  double a0 = 0.0, a1 = 0.0;
+  long r = r0 + wid;
+  for (; r + 4 < r1; r += 8) {
+    a0 += chunk[r * nb + c] * v[r];
+    a1 += chunk[(r + 4) * nb + c] * v[r + 4];
+  }
+  if (r < r1) a0 += chunk[r * nb + c] * v[r];
+  red[wid][lane] = a0 + a1;
   __syncthreads();
-  if (wid == 0) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (wid == 0) part[(long)blockIdx.y * nb + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void chunk_tdot_finish_kernel(const double *__restrict__ part, int nslab, int nb,
+                                         double *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nb) return;
+  double s = 0.0;
+  for (int q = 0; q < nslab; ++q) s += part[(long)q * nb + c];
+  out[c] = s;
 }
 
+int64_t chunk_tdot_scratch(int64_t max_rows, int nb) { return (max_rows / TDOT_SLAB + 1) * (int64_t)nb; }
+
 void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
-                       double *out) {
-  hipLaunchKernelGGL(chunk_tdot_kernel, dim3(nb / 64), dim3(256), 0, s, chunk, (long)rows, nb, v, out);
+                       double *part, double *out) {
+  const int nslab = (int)((rows + TDOT_SLAB - 1) / TDOT_SLAB);
+  hipLaunchKernelGGL(chunk_tdot_kernel, dim3(nb / 64, nslab), dim3(256), 0, s, chunk, (long)rows, nb, v, part);
+  hipLaunchKernelGGL(chunk_tdot_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, part, nslab, nb, out);
 }
 
 // alpha partial of one rank: for every local row (local row block bi, global block

@@ -89,7 +89,7 @@ def test_sharded_grid_matches_single_gpu(grid):
         npad = (n + unit - 1) // unit * unit
         n2 = 3 * npad * npad * 8 // world
         mloc, nloc = npad // grid[0], npad // grid[1]
-        lin = 8 * (npad * 512 + 4 * (mloc + nloc) * 512 + (grid[1] // grid[0]) * nloc * 512
+        lin = 8 * (npad * 512 + 6 * (mloc + nloc) * 512 + (grid[1] // grid[0]) * nloc * 512
                    + npad * (D + 3) + mloc + 2 * npad + 1 + world)
         for b in outs:
             assert n2 <= b <= n2 + lin + (1 << 22), (b, n2, lin)
