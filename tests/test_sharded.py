@@ -95,6 +95,63 @@ def test_sharded_grid_matches_single_gpu(grid):
             assert n2 <= b <= n2 + lin + (1 << 22), (b, n2, lin)
 
 
+def expected_exchange_bytes(npad, grid, nb=512):
+    """Bytes sent over the transport by ONE sharded evaluation (all ranks together), from the
+    layout alone -- DESIGN.md section 5: per block column P the inverse of the diagonal tile goes
+    to every other rank; every rank of the owning process column sends its tiles of the L panel
+    (tile rows > P) to the Pc-1 ranks of its process row and, where Pr > 1, the tiles of grid
+    column pc' to the Pr-1 ranks (pr' != pr, pc'); the Y panel (tile rows <= P) the same way."""
+    Pr, Pc = grid
+    NB = npad // nb
+    mloc, nloc = NB // Pr, NB // Pc
+    first_gt = lambda P, p, Pn: (P - p) // Pn + 1 if P >= p else 0
+    blk = nb * nb * 8
+    total = 0
+    for P in range(NB):
+        total += (Pr * Pc - 1) * blk                       # D_P
+        for r in range(Pr):                                # sender (r, P mod Pc)
+            bi0 = first_gt(P, r, Pr)
+            total += (Pc - 1) * (mloc - bi0) * blk         # L panel along the process row
+            total += (Pc - 1) * bi0 * blk                  # Y panel along the process row
+            if Pr > 1:
+                for pc2 in range(r, Pc, Pr):               # grid columns whose tiles sit on this sender
+                    bj0 = first_gt(P, pc2, Pc)
+                    total += (Pr - 1) * ((nloc - bj0) + bj0) * blk
+    return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(1, 2), (2, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
+def test_sharded_exchange_volume_matches_the_layout(grid):
+    """The bytes that actually cross the transport in one Observe equal the count derived from
+    the 2-D block-cyclic layout (nothing is broadcast to ranks that do not need it)."""
+    from gogp_amd import kernel, synth
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    n, D = 3000, 2
+    X, y = synth.make_inputs(n, D, 77)
+    x = np.log([1.0, 0.5, 0.2])
+    world = grid[0] * grid[1]
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=X, Y=y, device=0, grid=grid,
+                       rank=r, world=world, exchange=lb.exchange, allreduce=lb.allreduce)
+        lml = sh.Observe(x)
+        sh.close()
+        return lml
+
+    outs, lb = loopback.run_ranks(world, rank_fn)
+    assert len(set(outs)) == 1
+    unit = 512 * grid[1]
+    npad = (n + unit - 1) // unit * unit
+    assert sum(lb.sent_bytes) == expected_exchange_bytes(npad, grid)
+    # per rank and evaluation this is 8 N^2 [(Pc-1)/(Pr Pc) + (Pr-1)/(Pr Pc)] + O(N) on average
+    Pr, Pc = grid
+    approx = 8 * npad * npad * ((Pc - 1) / (Pr * Pc) + (Pr - 1) / (Pr * Pc))
+    per_rank = sum(lb.sent_bytes) / world
+    assert abs(per_rank - approx) <= 0.02 * approx + (npad // 512) * 512 * 512 * 8
+
+
 @pytest.mark.gpu
 def test_sharded_not_positive_definite_reaches_every_rank():
     from gogp_amd import gp as G
