@@ -15,12 +15,16 @@ OPTS = [{}, {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}
         {"superpanel": 4, "eager": 0}]
 nrun = 0
 worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
+worst32 = dict(worst)
 while time.time() < t_end:
     name, D, simil, noise, ts, tn = CASES[rng.integers(0, len(CASES) - 1)]  # skip default_noise (cond 1e10)
     opts = OPTS[rng.integers(0, len(OPTS))]
-    g = G.GP(D, simil, noise)
+    prec = 32 if rng.integers(0, 5) == 0 else 64    # one run in five on the fp32 path (loose bounds)
+    g = G.GP(D, simil, noise, precision=prec)
     for k, v in opts.items():
         g.set_option(k, v)
+    tol = {"lml": 1e-8, "grad": 1e-6, "mu": 1e-6, "sigma": 1e-5} if prec == 64 else \
+          {"lml": 3e-4, "grad": 3e-3, "mu": 3e-2, "sigma": 3e-3}
     o = FastOracle(D, simil, noise)
     for rep in range(int(rng.integers(1, 5))):       # the same handle with changing data sizes
         n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
@@ -45,13 +49,20 @@ while time.time() < t_end:
              "grad": np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
              "mu": np.abs(mu - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
              "sigma": np.nanmax(np.abs(sigma - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
-        for k in e:
-            worst[k] = max(worst[k], float(e[k]))
-        if e["lml"] > 1e-8 or e["grad"] > 1e-6 or e["mu"] > 1e-6 or e["sigma"] > 1e-5:
-            print("MISMATCH", name, n, opts, order, e, flush=True)
+        if prec == 64:
+            for k in e:
+                worst[k] = max(worst[k], float(e[k]))
+        if any(e[k] > tol[k] for k in tol):
+            print("MISMATCH", name, n, opts, order, "precision", prec, e, flush=True)
             sys.exit(1)
+        if prec == 32:
+            for k in e:
+                worst32[k] = max(worst32[k], float(e[k]))
+            nrun += 1
+            continue
         nrun += 1
         if nrun % 100 == 0:
             print("  ... %d evaluations OK, %.0f s left" % (nrun, t_end - time.time()), flush=True)
     g.close()
-print("stress: %d evaluations OK in %.0f s; worst relative errors %s" % (nrun, seconds, worst), flush=True)
+print("stress: %d evaluations OK in %.0f s; worst relative errors fp64 %s; fp32 path %s" % (
+    nrun, seconds, worst, worst32), flush=True)

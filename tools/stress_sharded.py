@@ -1,0 +1,67 @@
+"""Randomised stress run of the 2-D sharded path (rank threads of one process over the callback transport)
+against the single-GPU path: random grids, sizes, kernel families, call orders."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import loopback
+from cases import CASES
+from gogp_amd import gp as G
+from gogp_amd.sharded import ShardedGP
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + seconds
+GRIDS = [(1, 1), (1, 2), (2, 2), (1, 3), (1, 4), (2, 4), (2, 6), (3, 3), (4, 4)]
+nrun = 0
+worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
+while time.time() < t_end:
+    name, D, simil, noise, ts, tn = CASES[rng.integers(0, len(CASES) - 1)]
+    grid = GRIDS[rng.integers(0, len(GRIDS))]
+    world = grid[0] * grid[1]
+    n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 4000), rng.integers(4000, 9000)]))
+    X = rng.uniform(0, 1, (n, D))
+    y = np.sin(2 * np.pi * X).sum(1) / np.sqrt(D) + 0.1 * rng.normal(size=n)
+    if n > 1:
+        y = (y - y.mean()) / y.std()
+    x = np.log(np.array(list(ts) + list(tn)) * np.exp(0.1 * rng.normal(size=len(ts) + len(tn))))
+    Z = rng.uniform(-0.1, 1.1, (int(rng.integers(1, 200)), D))
+    ref = G.GP(D, simil, noise, X=X, Y=y, device=0)
+    lml_o, grad_o = ref.Observe(x), ref.Gradient()
+    mu_o, sigma_o = ref.Produce(Z)
+    ref.close()
+    order = int(rng.integers(0, 3))
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, simil, noise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                       exchange=lb.exchange, allreduce=lb.allreduce)
+        lml = sh.Observe(x)
+        if order == 1:
+            lml = sh.Observe(x)
+        grad = sh.Gradient()
+        if order == 2:
+            sh.ThetaSimil, sh.ThetaNoise = list(np.exp(x[:len(ts)])), list(np.exp(x[len(ts):]))
+            sh.Absorb(X, y)
+            assert abs(sh.LML() - lml) <= 1e-12 * max(1.0, abs(lml))
+        mu, sigma = sh.Produce(Z)
+        sh.close()
+        return lml, grad, mu, sigma
+
+    outs, _ = loopback.run_ranks(world, rank_fn)
+    for lml, grad, mu, sigma in outs:
+        e = {"lml": abs(lml - lml_o) / max(1.0, abs(lml_o)),
+             "grad": np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
+             "mu": np.abs(mu - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
+             "sigma": np.nanmax(np.abs(sigma - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
+        for k in e:
+            worst[k] = max(worst[k], float(e[k]))
+        if e["lml"] > 1e-9 or e["grad"] > 1e-7 or e["mu"] > 1e-6 or e["sigma"] > 1e-5:
+            print("MISMATCH", name, n, grid, order, e, flush=True)
+            sys.exit(1)
+    nrun += 1
+    if nrun % 10 == 0:
+        print("  ... %d sharded evaluations OK (last: %s n=%d grid=%s), %.0f s left" % (
+            nrun, name, n, grid, t_end - time.time()), flush=True)
+print("sharded stress: %d evaluations OK in %.0f s; worst relative errors vs the single-GPU path %s" % (
+    nrun, seconds, worst), flush=True)
