@@ -23,6 +23,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [  # (n, D, kernel name)
     (700, 3, "rbf"), (2300, 2, "matern52"), (2600, 4, "ard"),
+    (1100, 24, "ard"),  # 17..32 ARD dimensions: the instance of the gradient kernel that once returned
+                        # wrong sums on the sharded path (grad.hip: launch_grad_reduce_local)
 ]
 
 
@@ -266,3 +268,25 @@ def test_loopback_transport_world2_cpu():
 
     outs, _ = loopback.run_ranks(2, rank_fn)
     assert outs == [True, True]
+
+
+def test_process_grid_and_exchange_formula_cpu():
+    """Host-side pieces of the sharded path that need no GPU: the default process grids
+    (1x1, 1x2, 2x2, 2x4, 4x4; Pr always divides Pc) and the exchange-volume count derived from
+    the layout against its closed form 8 N^2 [(Pc-1) + (Pr-1)] / (Pr Pc) per rank."""
+    import ctypes
+    from gogp_amd import _lib
+    L = _lib.lib()
+    want = {1: (1, 1), 2: (1, 2), 3: (1, 3), 4: (2, 2), 6: (1, 6), 8: (2, 4), 12: (2, 6), 16: (4, 4)}
+    for n, g in want.items():
+        pr, pc = ctypes.c_int(0), ctypes.c_int(0)
+        assert L.gogp_dist_grid(n, ctypes.byref(pr), ctypes.byref(pc)) == _lib.GOGP_OK
+        assert (pr.value, pc.value) == g and pc.value % pr.value == 0
+    assert L.gogp_dist_grid(0, ctypes.byref(pr), ctypes.byref(pc)) == _lib.GOGP_EARG
+    for grid in [(1, 2), (2, 2), (2, 4)]:
+        for npad in (16384, 32768):
+            Pr, Pc = grid
+            per_rank = expected_exchange_bytes(npad, grid) / (Pr * Pc)
+            closed = 8 * npad * npad * ((Pc - 1) + (Pr - 1)) / (Pr * Pc)
+            dterm = (npad // 512) * 512 * 512 * 8
+            assert closed <= per_rank <= closed + dterm

@@ -7,6 +7,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import loopback
 from cases import CASES
+from gogp_amd import kernel as _k
+CASES = [c for c in CASES if c[0] != "default_noise"] + [  # (cond 1e10: summation-order noise)
+                       ("ard24", 24, _k.Scaled(_k.ARD(_k.Normal, 24)), _k.UniformNoise, [1.1] + [2.0 + 0.05 * i for i in range(24)], [0.2]),
+                       ("ard40", 40, _k.Scaled(_k.ARD(_k.Normal, 40)), _k.UniformNoise, [1.1] + [2.5 + 0.03 * i for i in range(40)], [0.2]),
+                       ("rbf20", 20, _k.Scaled(_k.Normal), _k.UniformNoise, [1.0, 1.8], [0.15]), ("dummy", 1, None, None, [], [])]
 from gogp_amd import gp as G
 from gogp_amd.sharded import ShardedGP
 
