@@ -1014,7 +1014,10 @@ extern "C" int gogp_get_factor(gogp_handle *h, double *Lout) {
   if (!h || (h->n > 0 && !Lout)) return GOGP_EARG;
   if (h->n == 0) return GOGP_OK;
   if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
-  if (h->dist) return fail(h, GOGP_ESTATE, "L: not available on a sharded handle (tiles live on their ranks)");
+  if (h->dist) {  // collective: the tiles are gathered, every rank gets the whole factor
+    HIPCHK(h, hipSetDevice(h->device));
+    return gogp_dist_get_factor(h, Lout);
+  }
   HIPCHK(h, hipSetDevice(h->device));
   double *tmp = nullptr;
   HIPCHK(h, hipMalloc(&tmp, (size_t)h->n * h->n * sizeof(double)));

@@ -624,6 +624,50 @@ int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
   return GOGP_OK;
 }
 
+// ---- gp.GP.L of a sharded handle: gather the tiles (collective; every rank gets the whole factor) ---
+__global__ void scatter_tile_kernel(const double *__restrict__ src, int nb, double *__restrict__ dst, long n,
+                                    long row0, long col0, int diag) {
+  const long r = row0 + blockIdx.x;
+  if (r >= n) return;
+  for (int c = threadIdx.x; c < nb; c += blockDim.x) {
+    const long gc = col0 + c;
+    if (gc < n && (!diag || gc <= r)) dst[r * n + gc] = src[(long)blockIdx.x * nb + c];
+  }
+}
+
+int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
+  Dist2D *d = h->dist;
+  const int nb = d->nb;
+  const int64_t n = h->n;
+  for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, d->sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  double *tmp = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, (size_t)n * n * sizeof(double)));
+  hipError_t e = hipMemsetAsync(tmp, 0, (size_t)n * n * sizeof(double), d->sc);
+  for (int bj = 0; bj < d->nloc && e == hipSuccess; ++bj) {
+    const int gP = bj * d->Pc + d->pc;
+    for (int bi = 0; bi < d->mloc; ++bi) {
+      const int gI = bi * d->Pr + d->pr;
+      if (gI < gP || (int64_t)gI * nb >= n || (int64_t)gP * nb >= n) continue;
+      hipLaunchKernelGGL(scatter_tile_kernel, dim3(nb), dim3(256), 0, d->sc,
+                         d->lchunk(bj) + (size_t)bi * nb * nb, nb, tmp, (long)n, (long)gI * nb, (long)gP * nb,
+                         gI == gP ? 1 : 0);
+    }
+  }
+  int rc = GOGP_OK;
+  std::string terr;
+  if (e == hipSuccess) rc = d->tr->allreduce(d->sc, tmp, n * n, &terr);
+  if (e == hipSuccess && rc == GOGP_OK)
+    e = hipMemcpyAsync(Lout, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, d->sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->sc);
+  (void)hipFree(tmp);
+  if (rc != GOGP_OK) {
+    h->err = "sharded get_factor: " + terr;
+    return rc;
+  }
+  HIPCHK(h, e);
+  return GOGP_OK;
+}
+
 // ---- Produce on a sharded handle -----------------------------------------------------------------
 // gp.GP.Produce (gp/gp.go:258-360) with L never leaving its ranks:  sigma_j^2 = k(z_j, z_j) -
 // |L^-1 k*_j|^2 and L^-1 = Y^T, so with V = Y^T Kstar:  V[P-block, j] = sum_{I <= P} Y[I, P]^T

@@ -24,7 +24,7 @@ template <int ARD_D, bool LOCAL, class KT>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
     const double *__restrict__ alpha, const KT *__restrict__ Kinv, long ld, long n, int nt,
-    int ntiles, double *__restrict__ partials, int ntc, BlockMap map) {
+    int ntiles, double *__restrict__ partials, int ntc, BlockMap map, int ard0) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
         const double wgt = (gj < gi) ? 2.0 * w : w;
         const double *ri = Ri + r * D;
         simil_grad_accum<ARD_D>(
-            P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; }, wgt, acc, ard);
+            P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; }, wgt, acc, ard, ard0);
         if (gi == gj) acc[ACC_TRACE] += w;
       }
     }
@@ -108,11 +108,14 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
     }
   }
   __syncthreads();
+  // the pass over the first ARD dimensions (ard0 == 0) writes every slot (zeros in the dead ones),
+  // a later pass only the slots of its own dimensions
   if (tid < NACC) {
+    const bool base = tid <= ACC_TRACE, mine = tid >= ACC_ARD0 && tid < ACC_ARD0 + ARD_D;
     double v = 0.0;
-    const bool live = (tid <= ACC_TRACE) || (tid >= ACC_ARD0 && tid < ACC_ARD0 + ARD_D);
-    if (live) v = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-    partials[(long)blockIdx.x * NACC + tid] = v;
+    if (base || mine) v = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+    if (ard0 == 0) partials[(long)blockIdx.x * NACC + tid] = v;
+    else if (mine && tid + ard0 < NACC) partials[(long)blockIdx.x * NACC + tid + ard0] = v;
   }
 }
 
@@ -145,14 +148,17 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
-#define GOGP_LAUNCH_GR(AD)                                                                      \
+// More than 16 ARD dimensions: passes of 16 per-dimension accumulators each.  (Instances with 32 / 64
+// accumulators need more than 256 VGPRs; the code hipcc (ROCm 7.2) generates for them -- VGPRs that carry
+// SGPR spill lanes copied through AGPRs -- returned wrong, run-to-run varying sums on the sharded
+// path at N >= 4096: tools/grad_probe.py.)
+#define GOGP_LAUNCH_GR(AD, A0)                                                                    \
   hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap())
-  if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
-  else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
-  else if (ard_dims <= 16) GOGP_LAUNCH_GR(16);
-  else if (ard_dims <= 32) GOGP_LAUNCH_GR(32);
-  else GOGP_LAUNCH_GR(64);
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0)
+  if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
+  else
+    for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
 #undef GOGP_LAUNCH_GR
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
 }
@@ -180,18 +186,13 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
-#define GOGP_LAUNCH_GRL(AD)                                                                       \
+#define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
   hipLaunchKernelGGL((grad_reduce_kernel<AD, true, double>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map)
-  // No 32-accumulator instance here: with the extra index arithmetic of the block map that
-  // instance needs 256 VGPRs + AGPR and SGPR spills, and the code hipcc (ROCm 7.2) generates for
-  // it returned wrong, run-to-run varying sums (tools/sharded_big.py 5 2x4 found it; the 16- and
-  // 64-accumulator instances and every instance of the unsharded kernel are exact and
-  // deterministic).  17..32 ARD dimensions take the 64-accumulator instance.
-  if (ard_dims <= 0) GOGP_LAUNCH_GRL(0);
-  else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8);
-  else if (ard_dims <= 16) GOGP_LAUNCH_GRL(16);
-  else GOGP_LAUNCH_GRL(64);
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0)
+  if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
+  else
+    for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
 }

@@ -148,3 +148,4 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n);  // sizes + buffers of this r
 int gogp_dist_factorize(gogp_handle *h, bool want_kinv);
 int gogp_dist_gradient_sums(gogp_handle *h, double *hacc /* NACC, pinned host */);
 int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma);
+int gogp_dist_get_factor(gogp_handle *h, double *Lout /* n*n, every rank */);

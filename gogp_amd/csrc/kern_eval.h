@@ -69,10 +69,10 @@ __device__ __forceinline__ double simil_value(const DevParams &P, FA xa, FB xb) 
 
 // Accumulate  wgt * (theta_p dk/dtheta_p)  into the slot accumulators:
 //   acc[3t+0] scale, acc[3t+1] length (non-ARD), acc[3t+2] period,
-//   ard[d] per-dimension length of the (single) ARD term.
+//   ard[q] per-dimension length of the (single) ARD term, dimensions ard0 .. ard0 + ARD_D - 1.
 template <int ARD_D, class FA, class FB>
 __device__ __forceinline__ void simil_grad_accum(const DevParams &P, FA xa, FB xb, double wgt,
-                                                 double *acc, double *ard) {
+                                                 double *acc, double *ard, int ard0 = 0) {
   const int D = P.ndim;
 #pragma unroll
   for (int t = 0; t < GOGP_MAX_TERMS; ++t) {
@@ -98,11 +98,13 @@ __device__ __forceinline__ void simil_grad_accum(const DevParams &P, FA xa, FB x
       if (P.ard[t]) {
         if (ARD_D > 0) {
 #pragma unroll
-          for (int d = 0; d < ARD_D; ++d)
+          for (int q = 0; q < ARD_D; ++q) {
+            const int d = ard0 + q;
             if (d < D) {
               const double dd = sin(w * fabs(xa(d) - xb(d))) * P.inv_len[t][d];
-              ard[d] += cf * 4.0 * dd * dd;
+              ard[q] += cf * 4.0 * dd * dd;
             }
+          }
         }
       } else {
         acc[3 * t + 1] += cf * 4.0 * s;
@@ -120,11 +122,13 @@ __device__ __forceinline__ void simil_grad_accum(const DevParams &P, FA xa, FB x
       if (P.ard[t]) {
         if (ARD_D > 0) {
 #pragma unroll
-          for (int d = 0; d < ARD_D; ++d)
+          for (int q = 0; q < ARD_D; ++q) {
+            const int d = ard0 + q;
             if (d < D) {
               const double u = (xa(d) - xb(d)) * P.inv_len[t][d];
-              ard[d] += g * u * u;
+              ard[q] += g * u * u;
             }
+          }
         }
       } else {
         acc[3 * t + 1] += g * s;

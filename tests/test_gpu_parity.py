@@ -257,6 +257,31 @@ def test_full_form_gradient_at_max_ndim(gpmod, D):
     np.testing.assert_allclose(g2.Gradient(), grad_o[:D + 2], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize("D,n", [(17, 900), (24, 900), (32, 900), (33, 900), (40, 4200), (64, 4200)])
+def test_ard_gradient_many_dimensions(gpmod, D, n):
+    """ARD kernels with more than 16 length scales: the fused gradient reduction keeps 16
+    per-dimension accumulators in registers and takes one pass per 16 dimensions; n = 4200 gives
+    every workgroup several tiles.  Against the oracle, and bit-for-bit repeatable."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(100 + D)
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise
+    th = np.concatenate([[1.1], np.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D)), [0.2]])
+    x = np.log(th)
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    o = FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    grads = []
+    for _ in range(3):
+        assert abs(g.Observe(x) - lml_o) <= 1e-9 * abs(lml_o)
+        grads.append(g.Gradient())
+    np.testing.assert_array_equal(grads[0], grads[1])
+    np.testing.assert_array_equal(grads[0], grads[2])
+    assert np.abs(grads[0] - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
+    g.close()
+
+
 def test_full_form_gradient_mid_size(gpmod):
     """Input/output gradient at a size that spans several 64-row tiles and 256-panels,
     against central differences of the HIP LML itself on a few coordinates."""

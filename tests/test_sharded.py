@@ -23,8 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [  # (n, D, kernel name)
     (700, 3, "rbf"), (2300, 2, "matern52"), (2600, 4, "ard"),
-    (1100, 24, "ard"),  # 17..32 ARD dimensions: the instance of the gradient kernel that once returned
-                        # wrong sums on the sharded path (grad.hip: launch_grad_reduce_local)
+    (1100, 24, "ard"),  # more than 16 ARD dimensions: several passes of the gradient reduction
 ]
 
 
@@ -44,6 +43,9 @@ def _reference(n, D, name):
     ref = G.GP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0)
     Z = synth.make_test_points(9, D, 5)
     out = dict(X=X, y=y, x=x, Z=Z, lml=ref.Observe(x), grad=ref.Gradient(), alpha=ref.Alpha)
+    if n <= 1200:
+        Lr = ref.L
+        out["K"] = Lr @ Lr.T
     out["mu"], out["sigma"] = ref.Produce(Z)
     ref.close()
     return out
@@ -80,6 +82,10 @@ def test_sharded_grid_matches_single_gpu(grid):
             assert abs(sh.LML() - ref["lml"]) <= 1e-10 * abs(ref["lml"])
             mu, sg = sh.Produce(ref["Z"])
             np.testing.assert_allclose(mu, ref["mu"], rtol=1e-8, atol=1e-10)
+            if n <= 1200:  # gp.GP.L of a sharded handle: the tiles are gathered (collective)
+                Lf = sh.L
+                assert np.abs(Lf @ Lf.T - ref["K"]).max() <= 1e-10 * np.abs(ref["K"]).max()
+                assert np.allclose(np.triu(Lf, 1), 0.0)
             nbytes = sh.local_bytes()
             sh.close()
             return nbytes
@@ -120,6 +126,34 @@ def expected_exchange_bytes(npad, grid, nb=512):
                     bj0 = first_gt(P, pc2, Pc)
                     total += (Pr - 1) * ((nloc - bj0) + bj0) * blk
     return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(1, 1), (1, 2)], ids=lambda g: "%dx%d" % g)
+def test_sharded_ard_gradient_many_tiles_per_workgroup(grid):
+    """40 ARD dimensions at a size where every workgroup of the local gradient reduction walks
+    several tiles: the case a 64-accumulator instance of that kernel got wrong (run-to-run
+    varying sums; tools/grad_probe.py), now three passes of 16 accumulators."""
+    from gogp_amd import kernel
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    n, D, name = 4700, 40, "ard"
+    ref = _reference(n, D, name)
+    simil = _simil(name, D)
+    world = grid[0] * grid[1]
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, simil, kernel.UniformNoise, X=ref["X"], Y=ref["y"], device=0, grid=grid,
+                       rank=r, world=world, exchange=lb.exchange, allreduce=lb.allreduce)
+        lml, grad = sh.Observe(ref["x"]), sh.Gradient()
+        sh.close()
+        return lml, grad
+
+    outs, _ = loopback.run_ranks(world, rank_fn)
+    for lml, grad in outs:
+        assert abs(lml - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+        assert np.abs(grad - ref["grad"]).max() <= 1e-8 * max(1.0, np.abs(ref["grad"]).max())
+        np.testing.assert_array_equal(grad, outs[0][1])
 
 
 @pytest.mark.gpu
