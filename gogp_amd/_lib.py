@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libgogp_hip.so")
 HOOKS_PATH = os.path.join(_HERE, "libgogp_testhooks.so")
 
 GOGP_OK, GOGP_EARG, GOGP_ENOTPD, GOGP_EHIP, GOGP_ESTATE, GOGP_ENOMEM, GOGP_ECOND = 0, 1, 2, 3, 4, 5, 6
+GOGP_MAX_CANDIDATES = 16
 
 #: every symbol include/gogp_hip.h declares: (name, restype, argtypes)
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -51,6 +52,8 @@ SYMBOLS = [
     ("gogp_gradient", ctypes.c_int, [_h, _dp, _i64]),
     ("gogp_observe_gradient_batch", ctypes.c_int,
      [ctypes.POINTER(_h), ctypes.c_int, _dp, _i64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
+    ("gogp_observe_gradient_candidates", ctypes.c_int,
+     [_h, ctypes.c_int, _dp, _i64, _dp, _dp, ctypes.POINTER(ctypes.c_int)]),
     ("gogp_produce", ctypes.c_int, [_h, _dp, _i64, _dp, _dp]),
     ("gogp_n", _i64, [_h]),
     ("gogp_get_alpha", ctypes.c_int, [_h, _dp]),

@@ -100,6 +100,18 @@ static void free_n_buffers(gogp_handle *h) {
   h->cap_y = 0;
 }
 
+static void free_cand_buffers(gogp_handle *h) {
+  (void)hipFree(h->cand_arena);
+  (void)hipHostFree(h->cand_hostP);
+  (void)hipHostFree(h->cand_hscal);
+  h->cand_arena = nullptr;
+  h->cand_hostP = nullptr;
+  h->cand_hscal = nullptr;
+  h->cand_stride = 0;
+  h->cand_cap_k = h->cand_host_k = 0;
+  h->cand_cap_npad = 0;
+}
+
 static void free_m_buffers(gogp_handle *h) {
   (void)hipFree(h->dZ);
   (void)hipFree(h->KsT);
@@ -187,6 +199,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   gogp_dist_destroy(h);
   free_n_buffers(h);
   free_m_buffers(h);
+  free_cand_buffers(h);
   (void)hipFree(h->scalars);
   (void)hipFree(h->dscr);
   (void)hipFree(h->info);
@@ -323,8 +336,8 @@ extern "C" int gogp_set_data_device(gogp_handle *h, const double *dX, const doub
 }
 
 // ---- parameters ---------------------------------------------------------------------------
-int gogp_upload_params(gogp_handle *h) {
-  DevParams &p = *h->hostP;
+// DevParams of the handle's current natural parameters (theta_s, theta_n)
+static void fill_params(const gogp_handle *h, DevParams &p) {
   const gogp_desc &d = h->desc;
   memset(&p, 0, sizeof p);
   p.ndim = d.ndim;
@@ -351,8 +364,37 @@ int gogp_upload_params(gogp_handle *h) {
     p.noise_var = d.noise_scale * sd * sd;  // kernel/noise.go:47-49
     p.dnoise = 2.0 * p.noise_var;
   }
+}
+
+int gogp_upload_params(gogp_handle *h) {
+  if (h->batch_k > 1) return GOGP_OK;  // a batched evaluation uploaded every candidate's parameters
+  fill_params(h, *h->hostP);
   HIPCHK(h, hipMemcpyAsync(h->devP, h->hostP, sizeof(DevParams), hipMemcpyHostToDevice, h->s));
   return GOGP_OK;
+}
+
+// ---- per-candidate copies of a batched evaluation (batch_k slots, cand_stride bytes apart; one
+// ---- plain call when no batch is active) ---------------------------------------------------------
+static hipError_t cand_memset(gogp_handle *h, void *dst, size_t bytes, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
+    e = hipMemsetAsync((char *)dst + (size_t)c * h->cand_stride, 0, bytes, s);
+  return e;
+}
+// shared source (y) into every candidate's copy
+static hipError_t cand_copy_in(gogp_handle *h, void *dst, const void *src, size_t bytes, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
+    e = hipMemcpyAsync((char *)dst + (size_t)c * h->cand_stride, src, bytes, hipMemcpyDeviceToDevice, s);
+  return e;
+}
+// device results of every candidate into its row of the pinned staging block (rows of NACC + 16 doubles)
+static hipError_t cand_d2h(gogp_handle *h, double *hdst, const void *dsrc, size_t bytes, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
+    e = hipMemcpyAsync(hdst + (size_t)c * (NACC + 16), (const char *)dsrc + (size_t)c * h->cand_stride, bytes,
+                       hipMemcpyDeviceToHost, s);
+  return e;
 }
 
 // bufY (Y = L^-T) is allocated on first use and tracked by its own capacity: the other
@@ -366,6 +408,47 @@ static int ensure_y(gogp_handle *h) {
   HIPCHK(h, hipMalloc(&h->bufY, (size_t)cap * (size_t)cap * h->esz()));
   h->cap_y = cap;
   return GOGP_OK;
+}
+
+// What the scalars of one factorisation say (row of the pinned staging block: [0] 2 sum log L_ii,
+// [1] z^T z, [3], [4] min / max L_ii, [5] fp64 log-determinant of the fp32 path, [6] y^T alpha of the
+// refined alpha, [8] first failing pivot + 1).
+struct FactorResult {
+  int rc = GOGP_OK;
+  double lml = 0.0, cond_lb = 1.0;
+  int64_t notpd = -1;
+  std::string msg;
+};
+static FactorResult judge_scalars(const gogp_handle *h, const double *hs, bool fp32, bool refine) {
+  FactorResult r;
+  long long info = 0;
+  memcpy(&info, hs + 8, sizeof info);
+  char buf[160];
+  if (info != 0) {
+    r.rc = GOGP_ENOTPD;
+    r.notpd = (int64_t)info - 1;
+    snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)", (long long)r.notpd);
+    r.msg = buf;
+    return r;
+  }
+  // fp32 path: the log-determinant summed from the fp64 diagonal-block factors
+  const double logdet = fp32 ? hs[5] : hs[0];
+  const double ztz = refine ? hs[6] : hs[1];  // y^T alpha (refined) / z^T z
+  // gp/gp.go:244-253
+  r.lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
+  // gonum's Cholesky solves return a Condition error when its condition estimate exceeds
+  // 1e16 (mat.ConditionTolerance), which gp/gp.go:233-236 passes on (Absorb: error, Observe:
+  // panic).  (max L_ii / min L_ii)^2 is a lower bound of cond_2(K); beyond 1e16 the matrix is
+  // numerically singular whatever the estimator.  The factor, alpha and LML stay available.
+  const double dmin = hs[3], dmax = hs[4];
+  r.cond_lb = (dmin > 0.0) ? (dmax / dmin) * (dmax / dmin) : INFINITY;
+  if (!(r.cond_lb <= h->cond_limit)) {
+    snprintf(buf, sizeof buf, "Condition: matrix singular or near-singular with condition number >= %.4e",
+             r.cond_lb);
+    r.msg = buf;
+    r.rc = GOGP_ECOND;
+  }
+  return r;
 }
 
 // ---- factorisation: Gram + blocked right-looking Cholesky + forward solve ----------------
@@ -482,7 +565,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   // the panel stream joins whatever the main stream still holds from the previous call
   // (bufA's last readers) and the parameter upload
   if (sp != s) order(h, EV_ENTRY, s, sp);
-  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(long long), sp));
+  HIPCHK(h, cand_memset(h, h->info, sizeof(long long), sp));
   // Gram matrix: the first super-panel's block columns on the panel stream -- the chain
   // starts ~30 us later instead of after the whole 0.5 ms build -- the rest on the main stream
   {
@@ -506,7 +589,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   const int SW = h->superpanel;
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
-  HIPCHK(h, hipMemcpyAsync(h->w, h->dy, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, cand_copy_in(h, h->w, h->dy, (size_t)npad * sizeof(double), sp));
   // The forward substitution z = L^-1 y needs each panel once it is final and nothing
   // needs z before the end: it runs on the low-priority stream, off the chain.
   hipStream_t sz = h->lookahead ? h->sl : sp;
@@ -607,8 +690,8 @@ static int factorize_t(gogp_handle *h, bool eager) {
     launch_dot(sp, h->dy, h->alpha, h->n, h->scalars + 6);
     order(h, EV_ALPHA, sp, s);
   }
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(h->hscal + 8, h->info, sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, cand_d2h(h, h->hscal, h->scalars, 7 * sizeof(double), s));
+  HIPCHK(h, cand_d2h(h, h->hscal + 8, h->info, sizeof(long long), s));
   if (refine) {
     if (eager) (void)hipEventRecord(ev(h, EV_TRTRI), st);
   } else if (eager) {
@@ -629,43 +712,29 @@ static int factorize_t(gogp_handle *h, bool eager) {
   h->alpha_pending = true;
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
-  long long info = 0;
-  memcpy(&info, h->hscal + 8, sizeof info);
-  if (info != 0) {
+  if (h->batch_k > 1) {  // the caller judges every candidate from its own row of hscal
+    h->factored = true;
+    h->have_alpha = true;
+    return GOGP_OK;
+  }
+  const FactorResult fr = judge_scalars(h, h->hscal, sizeof(T) == 4, refine);
+  if (fr.rc == GOGP_ENOTPD) {
     (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s2);
     (void)hipStreamSynchronize(h->sl);
     h->alpha_pending = false;
     h->trtri_done = h->trtri_pending = false;
-    h->notpd = (int64_t)info - 1;
-    char buf[160];
-    snprintf(buf, sizeof buf, "Factorize: matrix is not positive definite (pivot %lld)",
-             (long long)h->notpd);
-    h->err = buf;
+    h->notpd = fr.notpd;
+    h->err = fr.msg;
     return GOGP_ENOTPD;
   }
-  // fp32 path: the log-determinant summed from the fp64 diagonal-block factors
-  const double logdet = sizeof(T) == 4 ? h->hscal[5] : h->hscal[0];
-  const double ztz = refine ? h->hscal[6] : h->hscal[1];  // y^T alpha (refined) / z^T z
-  // gp/gp.go:244-253
-  h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
+  h->lml = fr.lml;
   h->factored = true;
   h->have_alpha = true;
-  // gonum's Cholesky solves return a Condition error when its condition estimate exceeds
-  // 1e16 (mat.ConditionTolerance), which gp/gp.go:233-236 passes on (Absorb: error, Observe:
-  // panic).  (max L_ii / min L_ii)^2 is a lower bound of cond_2(K); beyond 1e16 the matrix is
-  // numerically singular whatever the estimator.  The factor, alpha and LML stay available.
-  const double dmin = h->hscal[3], dmax = h->hscal[4];
-  h->cond_lb = (dmin > 0.0) ? (dmax / dmin) * (dmax / dmin) : INFINITY;
-  if (!(h->cond_lb <= h->cond_limit)) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "Condition: matrix singular or near-singular with condition number >= %.4e",
-             h->cond_lb);
-    h->err = buf;
-    return GOGP_ECOND;
-  }
-  return GOGP_OK;
+  h->cond_lb = fr.cond_lb;
+  if (fr.rc == GOGP_ECOND) h->err = fr.msg;
+  return fr.rc;
 }
 
 static int factorize(gogp_handle *h, bool eager) {
@@ -812,6 +881,22 @@ static int64_t grad_len(const gogp_handle *h) {
   return h->with_obs ? h->P + h->n * (h->D + 1) : h->P;  // gp/gp.go:420-425
 }
 
+// d LML / d log theta from the slot sums of the fused reduction (common.h: ACC_*); out: P zeros
+static void assemble_gradient(const gogp_handle *h, const double *a, double dnoise, double *out) {
+  const gogp_desc &d = h->desc;
+  for (int t = 0; t < d.nterms; ++t) {
+    const gogp_term &T = d.terms[t];
+    if (T.scale_idx >= 0) out[T.scale_idx] += 0.5 * a[3 * t + 0];
+    if (T.ard) {
+      for (int j = 0; j < d.ndim; ++j) out[T.len_idx + j] += 0.5 * a[ACC_ARD0 + j];
+    } else {
+      out[T.len_idx] += 0.5 * a[3 * t + 1];
+    }
+    if (T.kind == GOGP_K_PERIODIC) out[T.period_idx] += 0.5 * a[3 * t + 2];
+  }
+  if (h->nn > 0) out[h->ns] = 0.5 * a[ACC_TRACE] * dnoise;
+}
+
 extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
   if (!h || !grad) return fail(h, GOGP_EARG, "gradient: NULL");
   if (!h->observed) return fail(h, GOGP_ESTATE, "Gradient before Observe");
@@ -842,25 +927,13 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
         launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
                            h->npad, h->gpart, h->gout);
     }
-    HIPCHK(h, hipMemcpyAsync(h->hscal + 16, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
   }
   if (!h->grad_valid) {
-    const double *a = h->hscal + 16;
     h->grad_cache.assign(h->P, 0.0);
-    const gogp_desc &d = h->desc;
-    for (int t = 0; t < d.nterms; ++t) {
-      const gogp_term &T = d.terms[t];
-      if (T.scale_idx >= 0) h->grad_cache[T.scale_idx] += 0.5 * a[3 * t + 0];
-      if (T.ard) {
-        for (int j = 0; j < d.ndim; ++j) h->grad_cache[T.len_idx + j] += 0.5 * a[ACC_ARD0 + j];
-      } else {
-        h->grad_cache[T.len_idx] += 0.5 * a[3 * t + 1];
-      }
-      if (T.kind == GOGP_K_PERIODIC) h->grad_cache[T.period_idx] += 0.5 * a[3 * t + 2];
-    }
-    if (h->nn > 0) h->grad_cache[h->ns] = 0.5 * a[ACC_TRACE] * h->hostP->dnoise;
+    assemble_gradient(h, h->hscal + 16, h->hostP->dnoise, h->grad_cache.data());
     h->grad_valid = true;
   }
   for (int i = 0; i < h->P; ++i) grad[i] = h->grad_cache[i];
@@ -908,6 +981,225 @@ extern "C" int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double
     if (status) status[i] = st[(size_t)i];
     if (first == GOGP_OK && st[(size_t)i] != GOGP_OK) first = st[(size_t)i];
   }
+  return first;
+}
+
+// ---- k candidates in ONE launch sequence ------------------------------------------------------------
+// The same use case with one handle: k hyper-parameter vectors on the handle's data (a line search's
+// trial points, the restarts of a multi-start optimisation).  Every kernel of the fused sweep is
+// launched once with the candidate index on gridDim.z (common.h: Batch): the dependent chain of one
+// evaluation (16 panel steps of ~230 us at N = 4096) is paid once for all k, and the GPU that one
+// chain cannot fill is filled by the others -- without the k x 5 streams of the threaded form above
+// competing for the hardware queues.  Each candidate works in its own arena slot; the handle's own
+// buffers and state (a previous Observe / Absorb) are left untouched.
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct CandLayout {
+  size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, total;
+};
+static CandLayout cand_layout(int64_t npad) {
+  CandLayout L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += align_up(bytes, 256);
+    return at;
+  };
+  const size_t nn = (size_t)npad * (size_t)npad * sizeof(double);
+  L.devP = take(sizeof(DevParams));
+  L.info = take(sizeof(long long));
+  L.scalars = take(8 * sizeof(double));
+  L.gout = take(NACC * sizeof(double));
+  L.z = take((size_t)npad * sizeof(double));
+  L.w = take((size_t)npad * sizeof(double));
+  L.alpha = take((size_t)npad * sizeof(double));
+  L.gpart = take((size_t)grad_reduce_blocks(npad) * NACC * sizeof(double));
+  L.Dinv = take((size_t)(npad / PANEL) * PANEL * PANEL * sizeof(double));
+  L.bufA = take(nn);
+  L.bufL = take(nn);
+  L.bufY = take(nn);
+  L.total = align_up(o, 4096);
+  return L;
+}
+
+static int ensure_candidates(gogp_handle *h, int k) {
+  if (k > h->cand_host_k) {
+    (void)hipHostFree(h->cand_hostP);
+    (void)hipHostFree(h->cand_hscal);
+    h->cand_hostP = nullptr;
+    h->cand_hscal = nullptr;
+    h->cand_host_k = 0;
+    HIPCHK(h, hipHostMalloc((void **)&h->cand_hostP, (size_t)k * sizeof(DevParams), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->cand_hscal, (size_t)k * (NACC + 16) * sizeof(double),
+                            hipHostMallocDefault));
+    h->cand_host_k = k;
+  }
+  if (k > h->cand_cap_k || h->npad > h->cand_cap_npad) {
+    (void)hipFree(h->cand_arena);
+    h->cand_arena = nullptr;
+    h->cand_cap_k = 0;
+    h->cand_cap_npad = 0;
+    const int64_t cap = std::max(h->npad, h->cand_cap_npad);
+    const CandLayout L = cand_layout(cap);
+    HIPCHK(h, hipMalloc((void **)&h->cand_arena, L.total * (size_t)k));
+    h->cand_stride = L.total;
+    h->cand_cap_k = k;
+    h->cand_cap_npad = cap;
+  }
+  return GOGP_OK;
+}
+
+extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const double *xs, int64_t len,
+                                                double *lmls, double *grads, int *status) {
+  if (!h || k <= 0 || !xs || !lmls || !grads) return fail(h, GOGP_EARG, "candidates: bad arguments");
+  if (k > GOGP_MAX_CANDIDATES) return fail(h, GOGP_EARG, "candidates: k > GOGP_MAX_CANDIDATES");
+  if (len != h->P) return fail(h, GOGP_EARG, "len(x)");  // gp/gp.go:398-400
+  if (!h->have_data) return fail(h, GOGP_ESTATE, "candidates: no data (gogp_set_data)");
+  if (h->dist) return fail(h, GOGP_EARG, "candidates: not available on a sharded handle");
+  if (h->prec != 64) return fail(h, GOGP_EARG, "candidates: fp64 path only");
+  if (!h->lookahead || !h->eager)
+    return fail(h, GOGP_EARG, "candidates: needs the fused sweep (options lookahead and eager on)");
+  if (h->n == 0) {  // gp/gp.go:101-104, 427-430
+    for (int c = 0; c < k; ++c) {
+      lmls[c] = 0.0;
+      if (status) status[c] = GOGP_OK;
+      for (int64_t i = 0; i < len; ++i) grads[(size_t)c * len + i] = 0.0;
+    }
+    return GOGP_OK;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  // nothing of the handle's own evaluation may still be running: its streams and events are reused
+  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_pending = h->alpha_pending = false;
+  int rc = ensure_candidates(h, k);
+  if (rc != GOGP_OK) return rc;
+
+  // ---- the handle works in arena slot 0 for the duration of the call ---------------------------------
+  struct Saved {
+    DevParams *devP;
+    long long *info;
+    double *scalars, *gout, *bufA, *bufL, *bufY, *Dinv, *z, *w, *alpha, *gpart, *hscal;
+    int64_t cap_y, notpd;
+    bool factored, have_alpha, have_kinv, observed, with_obs, grad_valid, trtri_done;
+    double lml, cond_lb;
+    std::vector<double> theta_s, theta_n;
+  } sv{h->devP, h->info, h->scalars, h->gout, h->bufA, h->bufL, h->bufY, h->Dinv, h->z, h->w, h->alpha,
+       h->gpart, h->hscal, h->cap_y, h->notpd, h->factored, h->have_alpha, h->have_kinv, h->observed,
+       h->with_obs, h->grad_valid, h->trtri_done, h->lml, h->cond_lb, h->theta_s, h->theta_n};
+  const CandLayout L = cand_layout(h->cand_cap_npad);
+  char *a0 = h->cand_arena;
+  h->devP = (DevParams *)(a0 + L.devP);
+  h->info = (long long *)(a0 + L.info);
+  h->scalars = (double *)(a0 + L.scalars);
+  h->gout = (double *)(a0 + L.gout);
+  h->bufA = (double *)(a0 + L.bufA);
+  h->bufL = (double *)(a0 + L.bufL);
+  h->bufY = (double *)(a0 + L.bufY);
+  h->Dinv = (double *)(a0 + L.Dinv);
+  h->z = (double *)(a0 + L.z);
+  h->w = (double *)(a0 + L.w);
+  h->alpha = (double *)(a0 + L.alpha);
+  h->gpart = (double *)(a0 + L.gpart);
+  h->hscal = h->cand_hscal;
+  h->cap_y = h->cand_cap_npad;
+  h->with_obs = false;
+  h->batch_k = k;
+  gogp::tl_batch.k = k;
+  gogp::tl_batch.stride = (long)h->cand_stride;
+  std::vector<int> st((size_t)k, GOGP_OK);
+
+  auto run = [&]() -> int {
+    // parameters of every candidate (gp/gp.go:378-385: theta = exp(x)); a candidate with unusable
+    // parameters is evaluated at theta = 1 and reported as GOGP_EARG
+    for (int c = 0; c < k; ++c) {
+      std::vector<double> th((size_t)h->P);
+      for (int i = 0; i < h->P; ++i) th[(size_t)i] = exp(xs[(size_t)c * len + i]);
+      if (set_theta_natural(h, th.data(), th.data() + h->ns) != GOGP_OK) {
+        st[(size_t)c] = GOGP_EARG;
+        std::fill(th.begin(), th.end(), 1.0);
+        (void)set_theta_natural(h, th.data(), th.data() + h->ns);
+      }
+      fill_params(h, h->cand_hostP[c]);
+      HIPCHK(h, hipMemcpyAsync((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c, sizeof(DevParams),
+                               hipMemcpyHostToDevice, h->s));
+    }
+    int r = factorize_t<double>(h, true);
+    if (r != GOGP_OK) return r;
+    r = compute_kinv_t<double>(h);
+    if (r != GOGP_OK) return r;
+    r = ensure_alpha(h);
+    if (r != GOGP_OK) return r;
+    {
+      AuxTimer tm(h, GOGP_PROF_GRAD, h->s);
+      launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n, h->npad,
+                         h->gpart, h->gout);
+    }
+    HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
+    for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+    HIPCHK(h, hipGetLastError());
+    return GOGP_OK;
+  };
+  rc = run();
+  if (rc != GOGP_OK)  // a HIP failure: drain before the buffers change hands again
+    for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) (void)hipStreamSynchronize(q);
+
+  std::string first_msg;
+  int first = rc;
+  if (rc == GOGP_OK) {
+    for (int c = 0; c < k; ++c) {
+      const double *hs = h->hscal + (size_t)c * (NACC + 16);
+      double *g = grads + (size_t)c * len;
+      for (int64_t i = 0; i < len; ++i) g[i] = 0.0;
+      lmls[c] = NAN;
+      if (st[(size_t)c] == GOGP_OK) {
+        const FactorResult fr = judge_scalars(h, hs, false, false);
+        st[(size_t)c] = fr.rc;
+        if (fr.rc != GOGP_ENOTPD) {
+          lmls[c] = fr.lml;
+          assemble_gradient(h, hs + 16, h->cand_hostP[c].dnoise, g);
+        }
+        if (fr.rc != GOGP_OK && first_msg.empty()) first_msg = fr.msg;
+      } else if (first_msg.empty()) {
+        first_msg = "candidates: parameters must be positive and finite";
+      }
+      if (first == GOGP_OK && st[(size_t)c] != GOGP_OK) first = st[(size_t)c];
+    }
+  }
+  if (status)
+    for (int c = 0; c < k; ++c) status[c] = (rc == GOGP_OK) ? st[(size_t)c] : rc;
+
+  // ---- back to the handle's own buffers and state -----------------------------------------------------
+  gogp::tl_batch.k = 1;
+  gogp::tl_batch.stride = 0;
+  h->batch_k = 1;
+  h->devP = sv.devP;
+  h->info = sv.info;
+  h->scalars = sv.scalars;
+  h->gout = sv.gout;
+  h->bufA = sv.bufA;
+  h->bufL = sv.bufL;
+  h->bufY = sv.bufY;
+  h->Dinv = sv.Dinv;
+  h->z = sv.z;
+  h->w = sv.w;
+  h->alpha = sv.alpha;
+  h->gpart = sv.gpart;
+  h->hscal = sv.hscal;
+  h->cap_y = sv.cap_y;
+  h->notpd = sv.notpd;
+  h->factored = sv.factored;
+  h->have_alpha = sv.have_alpha;
+  h->have_kinv = sv.have_kinv;
+  h->observed = sv.observed;
+  h->with_obs = sv.with_obs;
+  h->grad_valid = sv.grad_valid;
+  h->trtri_done = sv.trtri_done;
+  h->trtri_pending = h->alpha_pending = false;
+  h->lml = sv.lml;
+  h->cond_lb = sv.cond_lb;
+  h->theta_s = sv.theta_s;
+  h->theta_n = sv.theta_n;
+  if (first != GOGP_OK && rc == GOGP_OK) h->err = first_msg;
   return first;
 }
 

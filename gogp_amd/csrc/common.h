@@ -36,6 +36,22 @@ constexpr int ACC_TRACE = 3 * GOGP_MAX_TERMS;
 constexpr int ACC_ARD0 = 16;
 constexpr int NACC = ACC_ARD0 + GOGP_MAX_NDIM;
 
+// Candidate batching (gogp_observe_gradient_candidates): one launch sequence evaluates k hyper-
+// parameter candidates on the same data.  Every per-candidate buffer of candidate c lies
+// c * stride BYTES after candidate 0's (one arena slot per candidate, api.hip); the launchers
+// below that are on the Observe + Gradient path put the candidate index on gridDim.z and the
+// kernels shift their per-candidate pointers by blockIdx.z * stride.  Inputs (X, y) are shared.
+// The orchestrating thread sets tl_batch for the duration of the call; {1, 0} otherwise.
+struct Batch {
+  int k = 1;
+  long stride = 0;
+};
+inline thread_local Batch tl_batch;
+template <class P>
+__device__ __forceinline__ P *cand(P *p, long bstride) {
+  return (P *)((const char *)p + (long)blockIdx.z * bstride);
+}
+
 struct GemmProfile {
   bool on = false;
   std::vector<hipEvent_t> pool;

@@ -54,6 +54,7 @@ struct GemmArgs {
   // or gI == gJ and the tile is on/below the diagonal of that block); rule 2 additionally
   // overwrites (beta = 0) the tiles of row block gI == beta0 and accumulates into the others.
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;
+  long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     if (nkt <= 0) return;  // whole-workgroup exit (tile-uniform)
   }
 
-  const double *Ag = g.A + (long)ti * BT * g.lda + kbeg;
-  const double *Bg = g.B + (long)tj * BT * g.ldb + kbeg;
+  const double *Ag = cand(g.A, g.bstride) + (long)ti * BT * g.lda + kbeg;
+  const double *Bg = cand(g.B, g.bstride) + (long)tj * BT * g.ldb + kbeg;
 
   // ---- staging map: thread -> (row, 16-B chunk), NQ rows per operand --------
   const int srow = tid >> 3;  // 0..SROWS-1, +SROWS*q
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   for (int kk = 0; kk < 4; ++kk) xk[kk] = (((kk * 2 + fchunk) ^ ((frow >> 1) & 7)) << 1) + fhalf;
 
   // C fragment of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WTN;
+  double *Cg = cand(g.C, g.bstride) + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WTN;
   // address = wave-uniform row base (SGPRs) + ONE 32-bit per-lane offset + immediate: per-lane
   // 64-bit row pointers kept across the k loop spill, and a spill reload in the epilogue
   // waits (vmcnt counts stores too) for every C store issued before it
@@ -264,6 +265,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.rule = 0;
   g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
   g.Pr = g.Pc = 1;
+  g.bstride = tl_batch.stride;
+  const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
     g.rule = grid->rule;
     g.tpb_shift = grid->tpb_shift;
@@ -316,7 +319,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     }
     e0 = prof->pool[prof->used++];
     e1 = prof->pool[prof->used++];
-    prof->flops += flops;
+    prof->flops += flops * nz;
     prof->launches += 1;
   }
   // With profiling on, the two events ride on the kernel's own dispatch packet
@@ -341,11 +344,11 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)
-      GOGP_LAUNCH(dim3(n64), dim3(256), dgemm_nt_kernel<GEMM_RECT, 64, 4>);
+      GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_RECT, 64, 4>);
     else
-      GOGP_LAUNCH(dim3(n64), dim3(256), dgemm_nt_kernel<GEMM_LOWER, 64, 4>);
+      GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_LOWER, 64, 4>);
   } else if (mode == GEMM_LAUUM || ntiles >= 3072) {
-    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block8(512);
+    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles, 1, nz), block8(512);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_RECT, 128, 8>);
     else if (mode == GEMM_LOWER)
@@ -353,7 +356,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     else
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_LAUUM, 128, 8>);
   } else {
-    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block(256);
+    const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles, 1, nz), block(256);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block, dgemm_nt_kernel<GEMM_RECT, 128, 4>);
     else

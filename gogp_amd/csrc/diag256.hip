@@ -593,7 +593,11 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
                                                        double *__restrict__ Lout, long ldl,
                                                        double *__restrict__ Dinv, long row0,
                                                        long nvalid, long long *info,
-                                                       unsigned long long *stamps) {
+                                                       unsigned long long *stamps, long bstride) {
+  A = gogp::cand(A, bstride);  // candidate batching (common.h: Batch)
+  if (Lout) Lout = gogp::cand(Lout, bstride);
+  Dinv = gogp::cand(Dinv, bstride);
+  if (info) info = gogp::cand(info, bstride);
   __shared__ __attribute__((aligned(16))) double S[128 * SLD];
   __shared__ __attribute__((aligned(16))) double G[GSIZE];
   __shared__ double rinv_s[8 * 16];  // per-wave scratch of base16
@@ -602,9 +606,9 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
 
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
-  hipLaunchKernelGGL((diag256_kernel<true, false, 256>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
-                     (long)ldl, Dinv, (long)row0, (long)nvalid, info,
-                     (unsigned long long *)nullptr);
+  hipLaunchKernelGGL((diag256_kernel<true, false, 256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s,
+                     A, (long)ld, Lout, (long)ldl, Dinv, (long)row0, (long)nvalid, info,
+                     (unsigned long long *)nullptr, gogp::tl_batch.stride);
 }
 
 #ifndef GOGP_BUILD_TESTHOOKS
@@ -612,14 +616,14 @@ void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lo
                           double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
   hipLaunchKernelGGL((diag256_kernel<true, false, 512>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
                      (long)ldl, Dinv, (long)row0, (long)nvalid, info,
-                     (unsigned long long *)nullptr);
+                     (unsigned long long *)nullptr, 0L);
 }
 #endif
 
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv) {
   hipLaunchKernelGGL((diag256_kernel<false, false, 256>), dim3(1), dim3(NT), 0, s, L, (long)ld,
                      (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
-                     (unsigned long long *)nullptr);
+                     (unsigned long long *)nullptr, 0L);
 }
 
 #ifdef GOGP_BUILD_TESTHOOKS
@@ -627,7 +631,7 @@ void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double 
 void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
                             long long *info, unsigned long long *stamps) {
   hipLaunchKernelGGL((diag256_kernel<true, true, 256>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
-                     Dinv, 0L, 256L, info, stamps);
+                     Dinv, 0L, 256L, info, stamps, 0L);
 }
 #endif
 

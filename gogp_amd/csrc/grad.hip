@@ -24,9 +24,12 @@ template <int ARD_D, bool LOCAL, class KT>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
     const double *__restrict__ alpha, const KT *__restrict__ Kinv, long ld, long n, int nt,
-    int ntiles, double *__restrict__ partials, int ntc, BlockMap map, int ard0) {
+    int ntiles, double *__restrict__ partials, int ntc, BlockMap map, int ard0, long bstride) {
   extern __shared__ double sm[];
-  const DevParams &P = *Pp;
+  const DevParams &P = *cand(Pp, bstride);  // candidate batching (common.h: Batch); X is shared
+  alpha = cand(alpha, bstride);
+  Kinv = cand(Kinv, bstride);
+  partials = cand(partials, bstride);
   const int D = P.ndim;
   double *Ri = sm;              // [64][D]
   double *CjT = sm + 64 * D;    // [D][64]
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
 // out[q] = sum over blocks of partials[b][q]; one workgroup per slot q, fixed
 // summation tree (bitwise reproducible)
 __global__ __launch_bounds__(256) void grad_final_kernel(const double *__restrict__ partials,
-                                                         int nblocks, double *__restrict__ out) {
+                                                         int nblocks, double *__restrict__ out,
+                                                         long bstride) {
+  partials = cand(partials, bstride);  // candidate batching (common.h: Batch)
+  out = cand(out, bstride);
   __shared__ double red[4];
   const int q = blockIdx.x;
   double v = 0.0;
@@ -147,20 +153,21 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
+  const unsigned nz = (unsigned)tl_batch.k;
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 // More than 16 ARD dimensions: passes of 16 per-dimension accumulators each.  (Instances with 32 / 64
 // accumulators need more than 256 VGPRs; the code hipcc (ROCm 7.2) generates for them -- VGPRs that carry
 // SGPR spill lanes copied through AGPRs -- returned wrong, run-to-run varying sums on the sharded
 // path at N >= 4096: tools/grad_probe.py.)
 #define GOGP_LAUNCH_GR(AD, A0)                                                                    \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0)
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, alpha, \
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0, tl_batch.stride)
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
   else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
 #undef GOGP_LAUNCH_GR
-  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC, 1, nz), dim3(256), 0, s, partials, blocks, out, tl_batch.stride);
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
@@ -188,13 +195,13 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
   hipLaunchKernelGGL((grad_reduce_kernel<AD, true, double>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0)
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L)
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
   else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL
-  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out, 0L);
 }
 
 // ---- gradient w.r.t. the inputs (full Observe form) ------------------------------

@@ -24,9 +24,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
                                                    const double *__restrict__ Rsrc, long nrows,
                                                    const double *__restrict__ Csrc, long ncols,
                                                    T *__restrict__ Out, long ld, int ntc,
-                                                   int strip_w, int toff) {
+                                                   int strip_w, int toff, long bstride) {
   extern __shared__ double sm[];
-  const DevParams &P = *Pp;
+  const DevParams &P = *cand(Pp, bstride);  // candidate batching: parameters and output per candidate
+  Out = cand(Out, bstride);
   const int D = P.ndim;
   double *Ri = sm;            // [64][D]
   double *CjT = sm + 64 * D;  // [D][64]
@@ -222,7 +223,7 @@ static void gram_lower_t(hipStream_t s, const DevParams *p, int ndim, const doub
   const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
   hipLaunchKernelGGL((gram_kernel<false, T>), dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
-                     (long)n, K, (long)ld, nt, 0, 0);
+                     (long)n, K, (long)ld, nt, 0, 0, 0L);
 }
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
                        int64_t npad, double *K, int64_t ld) {
@@ -240,12 +241,13 @@ static void gram_lower_split_t(hipStream_t s_first, hipStream_t s_rest, const De
   int w = (int)(wcols / 64);
   if (w > nt) w = nt;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nt * w), dim3(256), lds, s_first, p, X, (long)n, X,
-                     (long)n, K, (long)ld, nt, w, 0);
+  const unsigned nz = (unsigned)tl_batch.k;
+  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nt * w, 1, nz), dim3(256), lds, s_first, p, X, (long)n, X,
+                     (long)n, K, (long)ld, nt, w, 0, tl_batch.stride);
   const int nr = nt - w;
   if (nr > 0)
-    hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nr * (nr + 1) / 2), dim3(256), lds, s_rest, p, X,
-                       (long)n, X, (long)n, K, (long)ld, nt, 0, w);
+    hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nr * (nr + 1) / 2, 1, nz), dim3(256), lds, s_rest, p, X,
+                       (long)n, X, (long)n, K, (long)ld, nt, 0, w, tl_batch.stride);
 }
 void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
                              const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
@@ -273,7 +275,7 @@ static void cross_t(hipStream_t s, const DevParams *p, int ndim, const double *X
   const int ntr = (int)(mpad / 64), ntc = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
   hipLaunchKernelGGL((gram_kernel<true, T>), dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
-                     (long)n, KsT, (long)ld, ntc, 0, 0);
+                     (long)n, KsT, (long)ld, ntc, 0, 0, 0L);
 }
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
                   int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT, int64_t ld) {

@@ -45,6 +45,17 @@ struct gogp_handle {
   hipStream_t s = nullptr;   // main stream: Gram, big trailing updates, reductions
   hipStream_t sp = nullptr;  // panel stream (high priority): diagonal blocks, TRSM-as-GEMM,
                              // skinny updates, substitution steps -- overlaps the big updates
+  // candidate batching (gogp_observe_gradient_candidates): k arena slots, each with its own copy of
+  // every per-candidate buffer at the same offset (common.h: Batch); the handle's own buffers are
+  // not touched by a batched evaluation
+  char *cand_arena = nullptr;
+  size_t cand_stride = 0;       // bytes per slot
+  int cand_cap_k = 0;
+  int64_t cand_cap_npad = 0;
+  DevParams *cand_hostP = nullptr;  // pinned, cand_host_k entries
+  double *cand_hscal = nullptr;     // pinned, cand_host_k x (NACC + 16) doubles
+  int cand_host_k = 0;
+  int batch_k = 1;              // > 1 only while a batched evaluation is being enqueued
   // sharded evaluation (gogp_dist_init_*): 2-D block-cyclic state, nullptr on a single GPU
   gogp::Dist2D *dist = nullptr;
   hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)

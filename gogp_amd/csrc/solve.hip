@@ -101,8 +101,12 @@ template <class T>
 __global__ __launch_bounds__(256) void trsv_fwd_kernel(const T *__restrict__ L, long ld,
                                                        const T *__restrict__ Dinv, int b,
                                                        double *__restrict__ w,
-                                                       double *__restrict__ z) {
+                                                       double *__restrict__ z, long bstride) {
   __shared__ double vb[256], zb[256], upd[128];
+  L = cand(L, bstride);  // candidate batching (common.h: Batch)
+  Dinv = cand(Dinv, bstride);
+  w = cand(w, bstride);
+  z = cand(z, bstride);
   const int tid = threadIdx.x;
   const int g = blockIdx.x;
   vb[tid] = w[(long)b * 256 + tid];
@@ -152,13 +156,13 @@ __global__ __launch_bounds__(256) void trsv_bwd_kernel(const T *__restrict__ L, 
 // nb = number of 256-blocks
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nb, double *w, double *z) {
-  hipLaunchKernelGGL(trsv_fwd_kernel<double>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
-                     Dinv, b, w, z);
+  hipLaunchKernelGGL(trsv_fwd_kernel<double>, dim3(2 + 2 * (nb - b - 1), 1, (unsigned)tl_batch.k), dim3(256), 0,
+                     s, L, (long)ld, Dinv, b, w, z, tl_batch.stride);
 }
 void launch_trsv_fwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv,
                           int b, int nb, double *w, double *z) {
   hipLaunchKernelGGL(trsv_fwd_kernel<float>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
-                     Dinv, b, w, z);
+                     Dinv, b, w, z, 0L);
 }
 
 void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
@@ -180,7 +184,10 @@ void launch_trsv_bwd_step(hipStream_t s, const float *L, int64_t ld, const float
 template <class T>
 __global__ __launch_bounds__(256) void alpha_from_y_kernel(const T *__restrict__ Y, long ld,
                                                            const double *__restrict__ z, long npad,
-                                                           double *__restrict__ alpha) {
+                                                           double *__restrict__ alpha, long bstride) {
+  Y = cand(Y, bstride);  // candidate batching (common.h: Batch)
+  z = cand(z, bstride);
+  alpha = cand(alpha, bstride);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 4 + wid;
   if (i >= npad) return;
@@ -203,14 +210,14 @@ __global__ __launch_bounds__(256) void alpha_from_y_kernel(const T *__restrict__
 void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha) {
   if (npad <= 0) return;
-  hipLaunchKernelGGL(alpha_from_y_kernel<double>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
-                     (long)ld, z, (long)npad, alpha);
+  hipLaunchKernelGGL(alpha_from_y_kernel<double>, dim3((unsigned)((npad + 3) / 4), 1, (unsigned)tl_batch.k),
+                     dim3(256), 0, s, Y, (long)ld, z, (long)npad, alpha, tl_batch.stride);
 }
 void launch_alpha_from_y(hipStream_t s, const float *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha) {
   if (npad <= 0) return;
   hipLaunchKernelGGL(alpha_from_y_kernel<float>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
-                     (long)ld, z, (long)npad, alpha);
+                     (long)ld, z, (long)npad, alpha, 0L);
 }
 
 // scalars[0] = sum_{i<n} 2 log L_ii ; scalars[1] = sum_{i<n} z_i^2 ;
@@ -220,7 +227,12 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const T *__restrict__
                                                            const double *__restrict__ z,
                                                            const double *__restrict__ y,
                                                            const double *__restrict__ alpha,
-                                                           long n, double *__restrict__ scalars) {
+                                                           long n, double *__restrict__ scalars,
+                                                           long bstride) {
+  L = cand(L, bstride);  // candidate batching (common.h: Batch); y is shared
+  z = cand(z, bstride);
+  if (alpha) alpha = cand(alpha, bstride);
+  scalars = cand(scalars, bstride);
   __shared__ double red[5][16];
   double a = 0.0, b = 0.0, c = 0.0, dmin = INFINITY, dmax = 0.0;
   for (long i = threadIdx.x; i < n; i += 1024) {
@@ -268,13 +280,13 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const T *__restrict__
 
 void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars) {
-  hipLaunchKernelGGL(lml_scalars_kernel<double>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
-                     (long)n, scalars);
+  hipLaunchKernelGGL(lml_scalars_kernel<double>, dim3(1, 1, (unsigned)tl_batch.k), dim3(1024), 0, s, L,
+                     (long)ld, z, y, alpha, (long)n, scalars, tl_batch.stride);
 }
 void launch_lml_scalars(hipStream_t s, const float *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars) {
   hipLaunchKernelGGL(lml_scalars_kernel<float>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
-                     (long)n, scalars);
+                     (long)n, scalars, 0L);
 }
 
 // one workgroup per row j < m: dot_j = sum_i V[j][i] vec[i], sq_j = sum_i V[j][i]^2
@@ -325,7 +337,8 @@ void launch_rownorm_dot(hipStream_t s, const float *V, int64_t ld, const double 
 // are not touched, so the two phases can share the buffer concurrently.
 template <class T>
 __global__ __launch_bounds__(256) void zero_upper_kernel(T *__restrict__ R, long ld,
-                                                         long npad) {
+                                                         long npad, long bstride) {
+  R = cand(R, bstride);  // candidate batching (common.h: Batch)
   const long row = blockIdx.y;
   const long cstart = (row / PANEL + 1) * PANEL;
   const long c = cstart + ((long)blockIdx.x * 256 + threadIdx.x) * 2;
@@ -335,20 +348,23 @@ __global__ __launch_bounds__(256) void zero_upper_kernel(T *__restrict__ R, long
 
 void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
   if (npad <= PANEL) return;
-  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
-  hipLaunchKernelGGL(zero_upper_kernel<double>, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+  dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL), (unsigned)tl_batch.k);
+  hipLaunchKernelGGL(zero_upper_kernel<double>, grid, dim3(256), 0, s, R, (long)ld, (long)npad,
+                     tl_batch.stride);
 }
 void launch_zero_upper_blocks(hipStream_t s, float *R, int64_t ld, int64_t npad) {
   if (npad <= PANEL) return;
   dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
-  hipLaunchKernelGGL(zero_upper_kernel<float>, grid, dim3(256), 0, s, R, (long)ld, (long)npad);
+  hipLaunchKernelGGL(zero_upper_kernel<float>, grid, dim3(256), 0, s, R, (long)ld, (long)npad, 0L);
 }
 
 // Y[c0+i][c0+j] = Dinv[j][i]  (256x256 transpose of a diagonal-block inverse into
 // the diagonal block of Y = L^-T)
 template <class T>
 __global__ __launch_bounds__(256) void ydiag_kernel(const T *__restrict__ Dinv,
-                                                    T *__restrict__ Y, long ld) {
+                                                    T *__restrict__ Y, long ld, long bstride) {
+  Dinv = cand(Dinv, bstride);  // candidate batching (common.h: Batch)
+  Y = cand(Y, bstride);
   __shared__ T tile[32][33];
   const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;  // 8x8 tiles of 32x32
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -360,15 +376,18 @@ __global__ __launch_bounds__(256) void ydiag_kernel(const T *__restrict__ Dinv,
 }
 
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld) {
-  hipLaunchKernelGGL(ydiag_kernel<double>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
+  hipLaunchKernelGGL(ydiag_kernel<double>, dim3(64, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv, Ydiag,
+                     (long)ld, tl_batch.stride);
 }
 void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld) {
-  hipLaunchKernelGGL(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld);
+  hipLaunchKernelGGL(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld, 0L);
 }
 
 // zero a rows x cols block (cols a multiple of 2, 16-B aligned)
 template <class T>
-__global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long ld, long cols) {
+__global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long ld, long cols,
+                                                         long bstride) {
+  B = cand(B, bstride);  // candidate batching (common.h: Batch)
   const long r = blockIdx.y;
   const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (c >= cols) return;
@@ -377,13 +396,14 @@ __global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long
 
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return;
-  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
-  hipLaunchKernelGGL(zero_block_kernel<double>, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows, (unsigned)tl_batch.k);
+  hipLaunchKernelGGL(zero_block_kernel<double>, grid, dim3(256), 0, s, B, (long)ld, (long)cols,
+                     tl_batch.stride);
 }
 void launch_zero_block(hipStream_t s, float *B, int64_t ld, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return;
   dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
-  hipLaunchKernelGGL(zero_block_kernel<float>, grid, dim3(256), 0, s, B, (long)ld, (long)cols);
+  hipLaunchKernelGGL(zero_block_kernel<float>, grid, dim3(256), 0, s, B, (long)ld, (long)cols, 0L);
 }
 
 __global__ void fill_kernel(double *p, long count, double v) {

@@ -184,6 +184,23 @@ int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double *x, int64_
                                 double *lmls /* k */, double *grads /* k*len */,
                                 int *status /* k */);
 
+/* k candidate parameter vectors on ONE handle's data, evaluated in one launch sequence: x is
+ * k x len row-major (len = P: log theta only), lmls[c] and grads[c*len ..] receive what
+ * gogp_observe + gogp_gradient would return for candidate c.  Every kernel of the sweep is launched
+ * once for all candidates (candidate index on the grid's z axis), so the dependent chain of small
+ * launches that bounds one evaluation below N ~ 8192 is paid once per batch.  Same counterpart as
+ * above (concurrently evaluated candidates of the reference's optimiser: a line search's trial
+ * points, multi-start restarts).  The handle's own state -- data, the factorisation of an earlier
+ * Absorb / Observe, Produce -- is not touched; the candidates live in k arena slots of
+ * ~3 x 8 N^2 bytes each that stay allocated until the handle is destroyed.  status[c] (may be
+ * NULL): GOGP_OK, GOGP_ENOTPD (lmls[c] = NaN, gradient zeros), GOGP_ECOND (values still
+ * returned) or GOGP_EARG (parameters not finite); the result is the first non-zero one.
+ * fp64 handles on one GPU only; k <= GOGP_MAX_CANDIDATES. */
+#define GOGP_MAX_CANDIDATES 16
+int gogp_observe_gradient_candidates(gogp_handle *h, int k, const double *x, int64_t len,
+                                     double *lmls /* k */, double *grads /* k*len */,
+                                     int *status /* k */);
+
 /* gp.GP.Produce (gp/gp.go:258-360): predictive mean and standard deviation of
  * the latent function at m points Z (row-major m x ndim).  sigma_j =
  * sqrt(k(z_j,z_j) - (Kstar^T K^-1 Kstar)_jj), unclamped like the reference

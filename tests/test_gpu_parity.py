@@ -715,6 +715,70 @@ def test_observe_gradient_batch_matches_single_calls(gpmod):
         g.close()
 
 
+@pytest.mark.parametrize("n,D,name", [(1200, 3, "matern32"), (700, 2, "periodic_sum"), (2100, 24, "ard"), (37, 1, "rbf")])
+def test_candidates_in_one_launch_sequence_match_single_calls(gpmod, n, D, name):
+    """gogp_observe_gradient_candidates: k parameter vectors in one launch sequence (candidate
+    index on the grid's z axis) give bit for bit what Observe + Gradient return one at a time --
+    the same kernels on the same data, only batched -- and leave the handle's own state alone."""
+    rng = np.random.default_rng(77 + n)
+    X, y = _data(rng, n, D)
+    noise = kernel.UniformNoise
+    simil = {"matern32": lambda: kernel.Scaled(kernel.Matern32), "rbf": lambda: kernel.Scaled(kernel.Normal),
+             "periodic_sum": lambda: kernel.Sum([kernel.Scaled(kernel.Normal), kernel.Scaled(kernel.Periodic)]),
+             "ard": lambda: kernel.Scaled(kernel.ARD(kernel.Normal, D))}[name]()
+    P = simil.NTheta() + 1
+    base = np.log(np.linspace(0.7, 1.3, P))
+    base[-1] = np.log(0.2)
+    k = 5
+    xs = base[None, :] + 0.15 * rng.normal(size=(k, P))
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    want = [(g.Observe(x), g.Gradient()) for x in xs]
+    lml_own, grad_own = g.Observe(base), g.Gradient()       # the handle's own state before the batch
+    Z = rng.uniform(0, 1, (7, D))
+    mu_own, sigma_own = g.Produce(Z)
+    for rep in range(2):
+        lmls, grads, status = g.observe_gradient_candidates(xs)
+        assert list(status) == [0] * k
+        for c in range(k):
+            assert lmls[c] == want[c][0], (c, lmls[c], want[c][0])
+            np.testing.assert_array_equal(grads[c], want[c][1])
+    # untouched: LML, cached gradient, Produce of the handle's own factorisation
+    assert g.LML() == lml_own
+    np.testing.assert_array_equal(g.Gradient(), grad_own)
+    mu2, sigma2 = g.Produce(Z)
+    np.testing.assert_array_equal(mu2, mu_own)
+    np.testing.assert_array_equal(sigma2, sigma_own)
+    # a smaller batch after a larger one, and a single candidate
+    lmls, grads, status = g.observe_gradient_candidates(xs[1:3])
+    assert lmls[0] == want[1][0] and lmls[1] == want[2][0]
+    lmls, grads, status = g.observe_gradient_candidates(xs[4])
+    assert lmls[0] == want[4][0]
+    np.testing.assert_array_equal(grads[0], want[4][1])
+    g.close()
+
+
+def test_candidates_one_not_positive_definite(gpmod):
+    """One candidate of a batch whose matrix is not positive definite: its status says so, the
+    others are unaffected (each candidate works in its own arena slot)."""
+    rng = np.random.default_rng(9)
+    X, y = _data(rng, 600, 2)
+    X[311] = X[17]  # a duplicated input: with a noise variance below one ulp of the kernel
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise  # variance the pivot is exactly 0
+    x_good, x_bad = np.log([1.0, 0.5, 0.2]), np.log([1.0, 0.5, 1e-13])
+    g = gpmod.GP(2, simil, noise, X=X, Y=y)
+    with pytest.raises(gpmod.FactorizeError):
+        g.Observe(x_bad)
+    want = (g.Observe(x_good), g.Gradient())
+    xs = np.stack([x_good, x_bad, x_good])
+    lmls, grads, status = g.observe_gradient_candidates(xs)
+    assert list(status) == [0, 2, 0]
+    assert np.isnan(lmls[1]) and not grads[1].any()
+    for c in (0, 2):
+        assert lmls[c] == want[0]
+        np.testing.assert_array_equal(grads[c], want[1])
+    g.close()
+
+
 def test_later_handles_as_fast_as_the_first(gpmod):
     """Stream sets are pooled (api.hip): a GP created after others were closed must run as
     fast as the first one.  With hipStreamDestroy + fresh streams every later handle of the
