@@ -159,6 +159,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--candidates", type=int, default=4,
                     help="N <= 8192: also time this many candidates evaluated concurrently")
+    ap.add_argument("--candidates-per-step", type=int, default=None,
+                    help="candidate thetas evaluated per step in ONE launch sequence "
+                         "(gogp_observe_gradient_candidates); default 8 for configs 1 and 2 (N <= 4096: one "
+                         "evaluation is a latency-bound chain), 1 otherwise")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300)
     args = ap.parse_args()
@@ -200,6 +204,11 @@ def main():
     peak = FP32_PEAK_TFLOPS if prec == 32 else FP64_PEAK_TFLOPS
     X, y = wl.inputs()
     simil, noise = wl.simil, wl.noise
+    cps = args.candidates_per_step
+    if cps is None:
+        cps = 8 if (args.config in (1, 2) and prec == 64 and not sharded_value) else 1
+    if cps > 1 and (prec != 64 or sharded_value):
+        raise SystemExit("--candidates-per-step > 1 needs the fp64 single-GPU path")
 
     def sync():
         gd.barrier()
@@ -235,6 +244,10 @@ def main():
         g.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
 
         def step(k):
+            if cps > 1:  # cps candidate thetas in one launch sequence
+                xs = np.array([wl.log_theta(k * cps + i, rank) for i in range(cps)])
+                lmls, grads, _ = g.observe_gradient_candidates(xs)
+                return float(lmls[-1]), grads[-1]
             lml = g.Observe(wl.log_theta(k, rank))
             grad = g.Gradient()
             return lml, grad
@@ -253,9 +266,13 @@ def main():
         grad_ms, grad_n = g.profile_read_aux(1)
         g.profile_enable(False)
         dt = gd.max_over_ranks(dt, device=red_dev)
-        value = world * steps / dt
+        value = world * steps * cps / dt
         par_text = ("1 evaluation per GPU" if world == 1 else
                     "replicas: %d independent evaluations (one candidate theta per GPU)" % world)
+        if cps > 1:
+            par_text = ("%d candidate thetas per step in ONE launch sequence per GPU (candidate index on the "
+                        "grid's z axis; gogp_observe_gradient_candidates)" % cps) + (
+                        "" if world == 1 else "; replicas: %d GPUs, independent batches" % world)
         scaling = "weak"
     else:
         from gogp_amd.sharded import ShardedGP
@@ -285,7 +302,7 @@ def main():
         scaling = "strong"
 
     if rank == 0:
-        algo_flops_step = float(N) ** 3  # N^3/3 Cholesky + 2N^3/3 inverse
+        algo_flops_step = float(N) ** 3 * cps  # N^3/3 Cholesky + 2N^3/3 inverse per evaluation
         # The kernel's launches overlap (several streams): its busy time is the union of the
         # event-timed launch intervals, not their sum.  On a sharded run the counters are rank
         # 0's and the algorithmic work per rank is N^3 / world.
@@ -313,6 +330,7 @@ def main():
                 "workload": wl.name + ", Observe+Gradient (hyperparameters-only form), theta perturbed "
                                       "every step",
                 "baseline_config": wl.config, "N": N, "D": D, "kernel": wl.kernel_text, "P": wl.P,
+                "candidates_per_step": cps,
                 "parallelism": par_text,
             },
             "lml": lml,
@@ -349,8 +367,8 @@ def main():
             out["roofline"]["traffic_note"] = tr.get("note")
         if gram_n and grad_n:
             w = 512  # the first super-panel's block columns are built on the panel stream
-            gram_bytes = 8.0 * max(0, N - w) ** 2 / 2.0
-            grad_bytes = 8.0 * float(N) * N / 2.0
+            gram_bytes = 8.0 * max(0, N - w) ** 2 / 2.0 * cps
+            grad_bytes = 8.0 * float(N) * N / 2.0 * cps
             out["hbm_bound_kernels"] = {
                 "gram_build": {"algorithmic_bytes": gram_bytes, "ms": gram_ms / gram_n,
                                "GBps": gram_bytes / (gram_ms / gram_n * 1e-3) / 1e9,
@@ -361,6 +379,22 @@ def main():
                 "note": "8 B per lower-triangle element written (Gram; the part built on the main "
                         "stream) / read (K^-1 in the fused gradient reduction); HIP events on the "
                         "kernel's stream"}
+        if cps > 1:
+            # the same workload one candidate at a time (the latency-bound chain `value` amortises)
+            g.Observe(wl.log_theta(0)); g.Gradient()
+            torch.cuda.synchronize()
+            reps = max(5, steps)
+            t1 = time.perf_counter()
+            for r in range(reps):
+                g.Observe(wl.log_theta(r)); g.Gradient()
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t1) / reps
+            out["single_candidate"] = {
+                "evals_per_s": 1.0 / t1, "ms_per_eval": t1 * 1e3,
+                "frac_wall": float(N) ** 3 / t1 / 1e12 / peak,
+                "note": "Observe + Gradient one theta at a time on the same handle (what a strictly "
+                        "sequential optimiser sees); `value` evaluates candidates_per_step thetas per "
+                        "launch sequence"}
         if world == 1 and N <= 8192 and args.candidates > 1:
             # below N ~ 8192 one evaluation is a chain of small dependent launches: k candidates
             # evaluated at once (gogp_observe_gradient_batch; the reference's optimiser can do the
@@ -382,7 +416,8 @@ def main():
             out["concurrent_candidates"] = {
                 "k": k, "evals_per_s": reps * k / tb, "ms_per_batch": tb / reps * 1e3,
                 "note": "k independent candidates evaluated at once on this GPU, one handle and one "
-                        "host thread each; `value` above is ONE candidate at a time"}
+                        "host thread each (gogp_observe_gradient_batch), for comparison with the "
+                        "one-launch-sequence form"}
             for gg in gps[1:]:
                 gg.close()
         if world == 1 and not args.no_produce and g is not None:

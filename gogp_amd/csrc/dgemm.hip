@@ -336,7 +336,9 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // workgroups and a quarter of the per-tile latency.  LAUUM keeps 128 (its K
   // ranges are cut at 128-row granularity).  Launches of >= 3072 tiles and LAUUM use the
   // 8-wave shape of the 128x128 tile (measured 4-9 % faster there), the rest the 4-wave one.
-  const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
+  // (a batched launch counts the tiles of all its candidates: together they fill the chip)
+  const long total_tiles = (long)ntiles * nz;
+  const bool small = (mode != GEMM_LAUUM) && (total_tiles < 384);
   if (small) {
     g.mt = mt * 2;
     g.nt = nt * 2;
@@ -347,7 +349,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
       GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_RECT, 64, 4>);
     else
       GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_LOWER, 64, 4>);
-  } else if (mode == GEMM_LAUUM || ntiles >= 3072) {
+  } else if (mode == GEMM_LAUUM || total_tiles >= 3072) {
     const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles, 1, nz), block8(512);
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_RECT, 128, 8>);
