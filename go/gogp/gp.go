@@ -293,6 +293,39 @@ func (gp *GP) Observe(x []float64) float64 {
 	return float64(lml)
 }
 
+// ObserveGradientCandidates evaluates k candidate log-theta vectors (hyperparameters-only form)
+// on the GP's data in ONE launch sequence and returns what Observe + Gradient would return for
+// each; the GP's own state is not touched.  status[c] is C.GOGP_ENOTPD where the matrix of
+// candidate c is not positive definite (lml NaN, gradient zeros).  This is the device-side
+// form of optimize.Settings.Concurrent (tutorial/tutorial.go:30,141): one GP instead of NTASKS.
+func (gp *GP) ObserveGradientCandidates(xs [][]float64) (lml []float64, grad [][]float64, status []int) {
+	k, p := len(xs), len(gp.ThetaSimil)+len(gp.ThetaNoise)
+	flat := make([]float64, k*p)
+	for c, x := range xs {
+		if len(x) != p {
+			panic("len(x)") // gp/gp.go:398-400
+		}
+		copy(flat[c*p:], x)
+	}
+	if err := gp.pushData(); err != nil {
+		panic(err)
+	}
+	lml = make([]float64, k)
+	gflat := make([]float64, k*p)
+	st := make([]C.int, k)
+	rc := C.gogp_observe_gradient_candidates(gp.handle(), C.int(k), dptr(flat), C.int64_t(p),
+		dptr(lml), dptr(gflat), &st[0])
+	if rc != C.GOGP_OK && rc != C.GOGP_ENOTPD && rc != C.GOGP_ECOND {
+		panic(gp.err(rc))
+	}
+	grad, status = make([][]float64, k), make([]int, k)
+	for c := range grad {
+		grad[c] = gflat[c*p : (c+1)*p]
+		status[c] = int(st[c])
+	}
+	return lml, grad, status
+}
+
 // Gradient computes the gradient of the log-likelihood (gp/gp.go:418-499).
 func (gp *GP) Gradient() []float64 {
 	grad := make([]float64, gp.lastLen)

@@ -121,6 +121,34 @@ class GP {
     return g;
   }
 
+  // k candidate log-theta vectors (hyperparameters-only form) on this GP's data in ONE launch
+  // sequence (gogp_observe_gradient_candidates); the GP's own state is not touched.  lml[c] is NaN
+  // and grad[c] zero where status[c] == GOGP_ENOTPD.  Counterpart: candidates evaluated
+  // concurrently by the reference's optimiser (optimize.Settings.Concurrent, tutorial/tutorial.go:30,141).
+  struct Candidates {
+    std::vector<double> lml;
+    std::vector<std::vector<double>> grad;
+    std::vector<int> status;
+  };
+  Candidates ObserveGradientCandidates(const std::vector<std::vector<double>> &xs) {
+    const size_t k = xs.size(), P = ThetaSimil.size() + ThetaNoise.size();
+    std::vector<double> flat(k * P), lml(k), grads(k * P);
+    for (size_t c = 0; c < k; ++c) {
+      if (xs[c].size() != P) throw Error(GOGP_EARG, "len(x)");
+      std::copy(xs[c].begin(), xs[c].end(), flat.begin() + (long)(c * P));
+    }
+    Candidates out;
+    out.status.assign(k, GOGP_OK);
+    check(push());
+    const int rc = gogp_observe_gradient_candidates(h_, (int)k, flat.data(), (int64_t)P, lml.data(), grads.data(),
+                                                    out.status.data());
+    if (rc != GOGP_OK && rc != GOGP_ENOTPD && rc != GOGP_ECOND) check(rc);
+    out.lml = lml;
+    for (size_t c = 0; c < k; ++c)
+      out.grad.emplace_back(grads.begin() + (long)(c * P), grads.begin() + (long)((c + 1) * P));
+    return out;
+  }
+
   // gp.GP.L (gp/gp.go:35): lower factor, row-major n x n, fetched on demand
   std::vector<double> Factor() {
     const size_t n = (size_t)gogp_n(h_);

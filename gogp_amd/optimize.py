@@ -57,14 +57,45 @@ def _is_not_positive_definite(e: Exception) -> bool:
 
 def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
           history_size: int = 10, max_step_log: float = 2.0,
-          callback: Optional[Callable[[int, np.ndarray, float], None]] = None) -> Result:
+          callback: Optional[Callable[[int, np.ndarray, float], None]] = None,
+          line_search_candidates: int = 1) -> Result:
     """Maximise m.Observe(x) (LML) over x = log theta with L-BFGS.
 
     ``m`` is a gogp_amd.gp.GP, a gogp_amd.gp.Model, or anything with
     Observe(x)/Gradient().  Stops when ||grad||_inf <= gradient_threshold
-    (gonum's GradientThreshold) or after major_iterations."""
+    (gonum's GradientThreshold) or after major_iterations.
+
+    ``line_search_candidates`` = k > 1: the backtracking line search evaluates its next k trial
+    steps (step, step/2, ...) in ONE launch sequence (GP.observe_gradient_candidates) and takes the
+    first that satisfies the Armijo condition -- the same accepted points, values and gradients
+    as k = 1, bit for bit, in fewer and better-filled passes over the GPU (the reference's
+    counterpart: optimize.Settings.Concurrent, tutorial/tutorial.go:30,141).  Hyperparameters-only
+    form; the GP ends at the returned point."""
     x = np.array(x0, dtype=float)
     evals = 0
+    kls = int(line_search_candidates)
+    gp_b = getattr(m, "GP", m)
+    priors_b = getattr(m, "Priors", None) if hasattr(m, "GP") else None
+    if kls > 1 and not hasattr(gp_b, "observe_gradient_candidates"):
+        raise ValueError("line_search_candidates needs a GP with observe_gradient_candidates")
+
+    def batch_value_and_grad(xs):
+        """(-LML - log prior, its gradient) per row of xs; inf / None where K is not usable."""
+        nonlocal evals
+        evals += len(xs)
+        lmls, grads, status = gp_b.observe_gradient_candidates(xs)
+        out = []
+        for c in range(len(xs)):
+            if status[c] != 0 or not np.isfinite(lmls[c]):
+                out.append((np.inf, None))
+                continue
+            v, gr = float(lmls[c]), np.array(grads[c], dtype=float)
+            if priors_b is not None:  # gp/model.go:17-28
+                v += priors_b.Observe(xs[c])
+                pg = np.asarray(priors_b.Gradient(), dtype=float)
+                gr[:len(pg)] += pg
+            out.append((-v, -gr) if np.isfinite(v) else (np.inf, None))
+        return out
 
     def value_and_grad(xx):
         nonlocal evals
@@ -123,16 +154,34 @@ def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
             step = min(step, 1.0 / max(1.0, np.abs(g).max()))
         slope = float(d @ g)
         accepted = False
-        for _ in range(30):
-            xn = x + step * d
-            fn, _ = value_and_grad(xn)
-            if np.isfinite(fn) and fn <= f + 1e-4 * step * slope:
-                accepted = True
-                break
-            step *= 0.5
+        gn = None
+        if kls > 1:
+            trials = 0
+            while trials < 30 and not accepted:
+                kk = min(kls, 30 - trials)
+                steps_c = step * 0.5 ** np.arange(kk)
+                res = batch_value_and_grad(x[None, :] + steps_c[:, None] * d[None, :])
+                for c in range(kk):
+                    fc, gc = res[c]
+                    if np.isfinite(fc) and fc <= f + 1e-4 * steps_c[c] * slope:
+                        accepted, step, fn, gn = True, steps_c[c], fc, gc
+                        xn = x + step * d
+                        break
+                trials += kk
+                if not accepted:
+                    step = steps_c[-1] * 0.5
+        else:
+            for _ in range(30):
+                xn = x + step * d
+                fn, _ = value_and_grad(xn)
+                if np.isfinite(fn) and fn <= f + 1e-4 * step * slope:
+                    accepted = True
+                    break
+                step *= 0.5
         if not accepted:
             break
-        gn = -np.asarray(m.Gradient(), dtype=float)
+        if gn is None:
+            gn = -np.asarray(m.Gradient(), dtype=float)
         s_vec, y_vec = xn - x, gn - g
         if float(s_vec @ y_vec) > 1e-12 * float(np.linalg.norm(s_vec) * np.linalg.norm(y_vec)):
             S.append(s_vec)
@@ -144,6 +193,8 @@ def lbfgs(m, x0, major_iterations: int = 1000, gradient_threshold: float = 1e-6,
         hist.append(-f)
         if callback:
             callback(it, x, -f)
+    if kls > 1:  # the candidates never touched the GP's own state: leave it at the returned point
+        m.Observe(x)
     return Result(x=x, lml=-f, grad=-g, iterations=it, evaluations=evals, converged=converged,
                   history=hist)
 

@@ -61,6 +61,21 @@ int main(void) {
   CHECK(gogp_gradient(h, grad2, 2));
   CHECK(gogp_observe(h, x1, 2, &lml3)); /* and back: identical result, no set_data in between */
   if (lml3 != lml || lml2 == lml) return printf("repeat %.17g %.17g %.17g\n", lml, lml2, lml3), 1;
+  /* the same two points as candidates of ONE launch sequence: bit-equal, handle state untouched */
+  {
+    const double xs[4] = {1.0, 1.0, 0.7, 1.2};
+    double lmls[2], grads[4], gnow[2];
+    int st[2] = {-1, -1};
+    CHECK(gogp_observe_gradient_candidates(h, 2, xs, 2, lmls, grads, st));
+    if (st[0] != GOGP_OK || st[1] != GOGP_OK || lmls[0] != lml || lmls[1] != lml2)
+      return printf("candidates %.17g %.17g vs %.17g %.17g\n", lmls[0], lmls[1], lml, lml2), 1;
+    if (grads[0] != grad[0] || grads[1] != grad[1] || grads[2] != grad2[0] || grads[3] != grad2[1])
+      return printf("candidate gradients differ\n"), 1;
+    CHECK(gogp_gradient(h, gnow, 2)); /* still the gradient of the last gogp_observe (x1) */
+    if (gnow[0] != grad[0] || gnow[1] != grad[1]) return printf("handle state changed\n"), 1;
+    if (gogp_observe_gradient_candidates(h, 2, xs, 3, lmls, grads, st) != GOGP_EARG) return 1;
+    if (gogp_observe_gradient_candidates(h, GOGP_MAX_CANDIDATES + 1, xs, 2, lmls, grads, st) != GOGP_EARG) return 1;
+  }
   CHECK(gogp_get_alpha(h, alpha));
   if (gogp_n(h) != 2) return 1;
   if (gogp_gradient(h, grad, 3) != GOGP_EARG) return printf("gradient length not checked\n"), 1;

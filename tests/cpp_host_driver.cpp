@@ -62,6 +62,13 @@ int main() {
     }
     std::vector<double> g = g2.Gradient();
     if (g.size() != 2) return 1;
+    // two candidates in one launch sequence: the current point and another one; the first must
+    // reproduce Observe + Gradient bit for bit and the GP's own state must survive
+    const double ll07 = g2.Observe({0.7, 1.2});
+    if (g2.Observe({1.0, 1.0}) != ll) return 1;
+    const gogp::GP::Candidates cd = g2.ObserveGradientCandidates({{1.0, 1.0}, {0.7, 1.2}});
+    if (cd.lml.size() != 2 || cd.lml[0] != ll || cd.lml[1] != ll07 || cd.status[0] != 0 || cd.status[1] != 0) return 1;
+    if (cd.grad[0] != g || g2.Gradient() != g) return 1;
     bool threw = false;
     try {
       g2.Observe({1.0, 1.0, 0.5});  // leftover 1 is not a multiple of NDim+1: gp/gp.go:398-400

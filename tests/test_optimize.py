@@ -107,3 +107,60 @@ def test_gp_model_with_priors():
         assert abs(fd - gr[i]) <= 1e-5 * max(1.0, abs(fd))
     r = optimize.lbfgs(m, x, gradient_threshold=1e-5, major_iterations=100)
     assert r.lml >= ll
+
+
+class _BatchedQuadratic(Quadratic):
+    """Quadratic with the candidates call of gogp_amd.gp.GP (CPU double)."""
+
+    def observe_gradient_candidates(self, xs):
+        xs = np.asarray(xs, dtype=float)
+        self.batches = getattr(self, "batches", 0) + 1
+        lmls = np.array([float(-0.5 * x @ self.A @ x + self.b @ x) for x in xs])
+        grads = np.array([-self.A @ x + self.b for x in xs])
+        return lmls, grads, np.zeros(len(xs), dtype=int)
+
+
+def test_lbfgs_batched_line_search_takes_the_same_path():
+    """line_search_candidates = k: the trial steps of a backtracking search evaluated k at a time
+    accept exactly the points the one-at-a-time search accepts."""
+    rng = np.random.default_rng(1)
+    M = rng.normal(size=(5, 5))
+    A = M @ M.T + 0.3 * np.eye(5)  # badly scaled: the line search backtracks
+    b = rng.normal(size=5) * 5
+    r1 = optimize.lbfgs(Quadratic(A, b), np.zeros(5), gradient_threshold=1e-7)
+    m4 = _BatchedQuadratic(A, b)
+    r4 = optimize.lbfgs(m4, np.zeros(5), gradient_threshold=1e-7, line_search_candidates=4)
+    assert r4.converged and r1.converged and r4.iterations == r1.iterations
+    np.testing.assert_allclose(r4.x, r1.x, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(r4.history, r1.history, rtol=1e-13)
+    assert m4.batches <= r1.evaluations
+    with pytest.raises(ValueError):
+        optimize.lbfgs(Quadratic(A, b), np.zeros(5), line_search_candidates=4)
+
+
+@pytest.mark.gpu
+def test_lbfgs_batched_line_search_on_gpu_is_bit_identical():
+    """On the GPU the candidates of one launch sequence are bit for bit the single evaluations,
+    so the batched line search returns the identical optimum -- for a GP and for a gp.Model with
+    priors -- and leaves the GP at it."""
+    from gogp_amd import gp as G
+    from gogp_amd import synth
+    n, D = 700, 2
+    X, y = synth.make_inputs(n, D, 78)
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    x0 = np.log([2.0, 0.2, 0.7])
+    g1 = G.GP(D, simil, noise, X=X, Y=y)
+    r1 = optimize.lbfgs(g1, x0, gradient_threshold=1e-5, major_iterations=60)
+    g4 = G.GP(D, simil, noise, X=X, Y=y)
+    r4 = optimize.lbfgs(g4, x0, gradient_threshold=1e-5, major_iterations=60, line_search_candidates=4)
+    np.testing.assert_array_equal(r4.x, r1.x)
+    assert r4.lml == r1.lml and r4.iterations == r1.iterations
+    assert g4.LML() == r4.lml  # the GP holds the factorisation of the returned point
+    pri = optimize.NormalLogPriors([0.0, -1.0, -2.0], [1.0, 1.0, 1.0])
+    m1, m4 = G.Model(g1, pri), G.Model(g4, optimize.NormalLogPriors([0.0, -1.0, -2.0], [1.0, 1.0, 1.0]))
+    q1 = optimize.lbfgs(m1, x0, gradient_threshold=1e-5, major_iterations=60)
+    q4 = optimize.lbfgs(m4, x0, gradient_threshold=1e-5, major_iterations=60, line_search_candidates=3)
+    np.testing.assert_allclose(q4.x, q1.x, rtol=0, atol=1e-12)
+    assert abs(q4.lml - q1.lml) <= 1e-12 * abs(q1.lml)
+    g1.close()
+    g4.close()

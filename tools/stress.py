@@ -42,6 +42,15 @@ while time.time() < t_end:
         grad = g.Gradient()
         if order == 2:
             grad = g.Gradient()                      # Gradient twice
+        if prec == 64 and "lookahead" not in opts and "eager" not in opts and rng.integers(0, 3) == 0:
+            # the same point plus perturbed ones as candidates of one launch sequence: bit-equal,
+            # and the handle's own state (checked by Produce below) untouched
+            kc = int(rng.integers(1, 6))
+            xs = np.stack([x] + [x + 0.05 * rng.normal(size=x.size) for _ in range(kc - 1)])
+            lmls, grads, st = g.observe_gradient_candidates(xs)
+            if st[0] != 0 or lmls[0] != lml or not np.array_equal(grads[0], grad):
+                print("MISMATCH candidates", name, n, opts, st, lmls[0], lml, flush=True)
+                sys.exit(1)
         Z = rng.uniform(-0.1, 1.1, (int(rng.integers(1, 300)), D))
         mu, sigma = g.Produce(Z)
         lml_o = o.Observe(x); grad_o = o.Gradient(); mu_o, sigma_o = o.Produce(Z)
