@@ -128,6 +128,54 @@ def expected_exchange_bytes(npad, grid, nb=512):
     return total
 
 
+def test_rendezvous_checker_finds_a_cyclic_wait():
+    """The checker itself: two ranks that each send first and receive in their NEXT group pass on
+    buffered queues and hang on RCCL; the same transfers in ONE group per rank are fine."""
+    import loopback
+    bad = [[("group", [(1, True, 8)]), ("group", [(1, False, 8)])],
+           [("group", [(0, True, 8)]), ("group", [(0, False, 8)])]]
+    good = [[("group", [(1, True, 8), (1, False, 8)]), ("allreduce", 16)],
+            [("group", [(0, True, 8), (0, False, 8)]), ("allreduce", 16)]]
+    skew = [[("group", [(1, True, 8)]), ("group", [(1, True, 8)]), ("allreduce", 8)],
+            [("group", []), ("group", [(0, False, 8)]), ("group", [(0, False, 8)]), ("allreduce", 8)]]
+    assert loopback.check_rendezvous(bad) is not None
+    assert loopback.check_rendezvous(good) is None
+    assert loopback.check_rendezvous(skew) is None
+    assert loopback.check_rendezvous([[("allreduce", 8)], [("allreduce", 16)]]) is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(1, 2), (2, 2), (1, 3), (2, 4), (4, 4), (2, 6)], ids=lambda g: "%dx%d" % g)
+def test_exchange_schedule_completes_without_buffering(grid):
+    """RCCL's grouped send / receive has rendezvous semantics; the rehearsal transports (queues,
+    gloo) buffer.  Replay what every rank asked of the transport during Observe + Gradient +
+    Produce under strict rendezvous rules: no cyclic wait, matching sizes, all-reduces aligned."""
+    from gogp_amd import kernel
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    world = grid[0] * grid[1]
+    for n in (700, 3300):
+        ref = _reference(n, 3, "rbf") if n == 700 else None
+        rng = np.random.default_rng(n)
+        X = ref["X"] if ref else rng.uniform(0, 1, (n, 3))
+        y = ref["y"] if ref else rng.normal(size=n)
+        x = np.log([1.0, 0.5, 0.3])
+        simil = _simil("rbf", 3)
+
+        def rank_fn(r, lb):
+            sh = ShardedGP(3, simil, kernel.UniformNoise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                           exchange=lb.exchange, allreduce=lb.allreduce)
+            sh.Observe(x)
+            sh.Gradient()
+            sh.Produce(rng.uniform(0, 1, (5, 3)) if False else np.full((5, 3), 0.25))
+            sh.Observe(x)  # a second evaluation right behind the first
+            sh.close()
+
+        _, lb = loopback.run_ranks(world, rank_fn)
+        verdict = loopback.check_rendezvous(lb.log)
+        assert verdict is None, (grid, n, verdict)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid", [(1, 1), (1, 2)], ids=lambda g: "%dx%d" % g)
 def test_sharded_ard_gradient_many_tiles_per_workgroup(grid):
