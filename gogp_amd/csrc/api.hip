@@ -100,7 +100,17 @@ static void free_n_buffers(gogp_handle *h) {
   h->cap_y = 0;
 }
 
+static void drop_cand_graph(gogp_handle *h) {
+  if (h->cand_graph) (void)hipGraphExecDestroy(h->cand_graph);
+  h->cand_graph = nullptr;
+}
+static void free_graph_stream(gogp_handle *h) {
+  if (h->sg) (void)hipStreamDestroy(h->sg);
+  h->sg = nullptr;
+}
+
 static void free_cand_buffers(gogp_handle *h) {
+  drop_cand_graph(h);
   (void)hipFree(h->cand_arena);
   (void)hipHostFree(h->cand_hostP);
   (void)hipHostFree(h->cand_hscal);
@@ -200,6 +210,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   free_n_buffers(h);
   free_m_buffers(h);
   free_cand_buffers(h);
+  free_graph_stream(h);
   (void)hipFree(h->scalars);
   (void)hipFree(h->dscr);
   (void)hipFree(h->info);
@@ -367,7 +378,7 @@ static void fill_params(const gogp_handle *h, DevParams &p) {
 }
 
 int gogp_upload_params(gogp_handle *h) {
-  if (h->batch_k > 1) return GOGP_OK;  // a batched evaluation uploaded every candidate's parameters
+  if (h->batch_mode) return GOGP_OK;  // a batched evaluation uploaded every candidate's parameters
   fill_params(h, *h->hostP);
   HIPCHK(h, hipMemcpyAsync(h->devP, h->hostP, sizeof(DevParams), hipMemcpyHostToDevice, h->s));
   return GOGP_OK;
@@ -710,13 +721,13 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipEventRecord(ev(h, EV_ALPHA), sp);
   }
   h->alpha_pending = true;
-  HIPCHK(h, hipStreamSynchronize(s));
-  HIPCHK(h, hipGetLastError());
-  if (h->batch_k > 1) {  // the caller judges every candidate from its own row of hscal
+  if (h->batch_mode) {  // the caller synchronises and judges every candidate from its own row of hscal
     h->factored = true;
     h->have_alpha = true;
     return GOGP_OK;
   }
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
   const FactorResult fr = judge_scalars(h, h->hscal, sizeof(T) == 4, refine);
   if (fr.rc == GOGP_ENOTPD) {
     (void)hipStreamSynchronize(sp);
@@ -993,6 +1004,7 @@ extern "C" int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double
 // competing for the hardware queues.  Each candidate works in its own arena slot; the handle's own
 // buffers and state (a previous Observe / Absorb) are left untouched.
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int64_t GRAPH_MAX_NPAD = 1024;  // option "graph": linear graphs only (see the capture below)
 
 struct CandLayout {
   size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, total;
@@ -1104,25 +1116,28 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   h->cap_y = h->cand_cap_npad;
   h->with_obs = false;
   h->batch_k = k;
+  h->batch_mode = true;
   gogp::tl_batch.k = k;
   gogp::tl_batch.stride = (long)h->cand_stride;
   std::vector<int> st((size_t)k, GOGP_OK);
 
-  auto run = [&]() -> int {
-    // parameters of every candidate (gp/gp.go:378-385: theta = exp(x)); a candidate with unusable
-    // parameters is evaluated at theta = 1 and reported as GOGP_EARG
-    for (int c = 0; c < k; ++c) {
-      std::vector<double> th((size_t)h->P);
-      for (int i = 0; i < h->P; ++i) th[(size_t)i] = exp(xs[(size_t)c * len + i]);
-      if (set_theta_natural(h, th.data(), th.data() + h->ns) != GOGP_OK) {
-        st[(size_t)c] = GOGP_EARG;
-        std::fill(th.begin(), th.end(), 1.0);
-        (void)set_theta_natural(h, th.data(), th.data() + h->ns);
-      }
-      fill_params(h, h->cand_hostP[c]);
+  // parameters of every candidate (gp/gp.go:378-385: theta = exp(x)) into pinned host memory; a
+  // candidate with unusable parameters is evaluated at theta = 1 and reported as GOGP_EARG
+  for (int c = 0; c < k; ++c) {
+    std::vector<double> th((size_t)h->P);
+    for (int i = 0; i < h->P; ++i) th[(size_t)i] = exp(xs[(size_t)c * len + i]);
+    if (set_theta_natural(h, th.data(), th.data() + h->ns) != GOGP_OK) {
+      st[(size_t)c] = GOGP_EARG;
+      std::fill(th.begin(), th.end(), 1.0);
+      (void)set_theta_natural(h, th.data(), th.data() + h->ns);
+    }
+    fill_params(h, h->cand_hostP[c]);
+  }
+  // the whole launch sequence: parameter upload, fused sweep, K^-1, gradient sums, results to the host
+  auto enqueue = [&]() -> int {
+    for (int c = 0; c < k; ++c)
       HIPCHK(h, hipMemcpyAsync((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c, sizeof(DevParams),
                                hipMemcpyHostToDevice, h->s));
-    }
     int r = factorize_t<double>(h, true);
     if (r != GOGP_OK) return r;
     r = compute_kinv_t<double>(h);
@@ -1135,6 +1150,76 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
                          h->gpart, h->gout);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
+    // every stream joins the main one (the end of a captured graph; harmless otherwise)
+    size_t slot = EV_BASE + 4 * (size_t)(h->npad / PANEL);  // the four event slots behind the panels' own
+    for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) order(h, slot++, q, h->s);
+    return GOGP_OK;
+  };
+  auto run = [&]() -> int {
+    int r = GOGP_OK;
+    const bool graph = h->use_graph && !h->prof.on && h->npad <= GRAPH_MAX_NPAD;
+    auto &key = h->cand_graph_key;
+    auto same = [&](const decltype(h->cand_graph_key) &q) {
+      return q.k == k && q.n == h->n && q.superpanel == h->superpanel && q.arena == h->cand_arena &&
+             q.dX == h->dX && q.dy == h->dy && q.hostP == h->cand_hostP && q.hscal == h->cand_hscal;
+    };
+    const bool hit = graph && h->cand_graph && same(key);
+    // capture only a sequence that was asked for twice in a row (an expanding-window loop changes n
+    // with every call: capturing each time would cost more than the replay saves)
+    const bool seen = graph && same(h->cand_seen_key);
+    h->cand_seen_key.k = k;
+    h->cand_seen_key.n = h->n;
+    h->cand_seen_key.superpanel = h->superpanel;
+    h->cand_seen_key.arena = h->cand_arena;
+    h->cand_seen_key.dX = h->dX;
+    h->cand_seen_key.dy = h->dy;
+    h->cand_seen_key.hostP = h->cand_hostP;
+    h->cand_seen_key.hscal = h->cand_hscal;
+    if (hit || seen) {
+      if (!hit) {
+        drop_cand_graph(h);
+        hipGraph_t gr = nullptr;
+        // Captured on ONE stream (the five work streams aliased to it for the duration): a linear
+        // graph.  hipStreamEndCapture of this ROCm (7.0 runtime bundled with torch) recurses without
+        // end on the sweep's fork / join pattern across streams, so the graph path is limited to
+        // sizes where the evaluation is a single dependent chain anyway (see the caller).
+        if (!h->sg) HIPCHK(h, hipStreamCreateWithFlags(&h->sg, hipStreamNonBlocking));
+        hipStream_t keep[5] = {h->s, h->sp, h->s2, h->st, h->sl};
+        h->s = h->sp = h->s2 = h->st = h->sl = h->sg;
+        const hipError_t eb = hipStreamBeginCapture(h->sg, hipStreamCaptureModeRelaxed);
+        hipError_t ec = eb;
+        if (eb == hipSuccess) {
+          r = enqueue();
+          ec = hipStreamEndCapture(h->sg, &gr);
+        }
+        h->s = keep[0];
+        h->sp = keep[1];
+        h->s2 = keep[2];
+        h->st = keep[3];
+        h->sl = keep[4];
+        if (r != GOGP_OK) {
+          if (gr) (void)hipGraphDestroy(gr);
+          return r;
+        }
+        HIPCHK(h, ec);
+        const hipError_t ei = hipGraphInstantiate(&h->cand_graph, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        HIPCHK(h, ei);
+        key.k = k;
+        key.n = h->n;
+        key.superpanel = h->superpanel;
+        key.arena = h->cand_arena;
+        key.dX = h->dX;
+        key.dy = h->dy;
+        key.hostP = h->cand_hostP;
+        key.hscal = h->cand_hscal;
+      }
+      HIPCHK(h, hipGraphLaunch(h->cand_graph, h->sg));
+      HIPCHK(h, hipStreamSynchronize(h->sg));
+    } else {
+      r = enqueue();
+      if (r != GOGP_OK) return r;
+    }
     for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
     HIPCHK(h, hipGetLastError());
     return GOGP_OK;
@@ -1172,6 +1257,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   gogp::tl_batch.k = 1;
   gogp::tl_batch.stride = 0;
   h->batch_k = 1;
+  h->batch_mode = false;
   h->devP = sv.devP;
   h->info = sv.info;
   h->scalars = sv.scalars;
@@ -1526,6 +1612,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
       h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
       h->trtri_done = h->trtri_pending = h->alpha_pending = false;
     }
+    return GOGP_OK;
+  }
+  if (strcmp(name, "graph") == 0) {  // candidates: replay a captured hipGraph instead of re-enqueueing
+    h->use_graph = value != 0;
+    if (!h->use_graph) drop_cand_graph(h);
     return GOGP_OK;
   }
   if (strcmp(name, "refine_steps") == 0) {

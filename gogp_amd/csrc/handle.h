@@ -56,6 +56,17 @@ struct gogp_handle {
   double *cand_hscal = nullptr;     // pinned, cand_host_k x (NACC + 16) doubles
   int cand_host_k = 0;
   int batch_k = 1;              // > 1 only while a batched evaluation is being enqueued
+  bool batch_mode = false;      // a batched evaluation is being enqueued (also with k = 1)
+  // option "graph": the launch sequence of a batched evaluation captured once into a hipGraph and
+  // replayed (the parameters change in pinned host memory only)
+  int use_graph = 1;
+  hipGraphExec_t cand_graph = nullptr;
+  hipStream_t sg = nullptr;     // capture / replay stream of that graph (created on first use)
+  struct {
+    int k = 0, superpanel = 0;
+    int64_t n = 0;
+    const void *arena = nullptr, *dX = nullptr, *dy = nullptr, *hostP = nullptr, *hscal = nullptr;
+  } cand_graph_key, cand_seen_key;  // what the graph was captured for / what the last call asked for
   // sharded evaluation (gogp_dist_init_*): 2-D block-cyclic state, nullptr on a single GPU
   gogp::Dist2D *dist = nullptr;
   hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)

@@ -748,6 +748,19 @@ def test_candidates_in_one_launch_sequence_match_single_calls(gpmod, n, D, name)
     mu2, sigma2 = g.Produce(Z)
     np.testing.assert_array_equal(mu2, mu_own)
     np.testing.assert_array_equal(sigma2, sigma_own)
+    # the same call again and again with other parameters and, in between, other data of the same
+    # size: up to N = 1024 the launch sequence is captured into a hipGraph on its second use and
+    # replayed from then on -- parameters and data must still be the current ones
+    for rep in range(4):
+        xs2 = base[None, :] + 0.1 * rng.normal(size=(k, P))
+        if rep == 2:
+            g.Y = y[::-1].copy()
+        lmls, grads, status = g.observe_gradient_candidates(xs2)
+        for c in (0, k - 1):
+            assert lmls[c] == g.Observe(xs2[c])
+            np.testing.assert_array_equal(grads[c], g.Gradient())
+    g.Y = y
+    g.Observe(base)
     # a smaller batch after a larger one, and a single candidate
     lmls, grads, status = g.observe_gradient_candidates(xs[1:3])
     assert lmls[0] == want[1][0] and lmls[1] == want[2][0]

@@ -9,6 +9,10 @@ nobs = int(sys.argv[2]) if len(sys.argv) > 2 else None
 wl = configs.workload(cfg, nobs)
 X, y = wl.inputs()
 g = G.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0)
+import os
+if os.environ.get("CAND_GRAPH"):
+    g.set_option("graph", 1)
+    print("hipGraph replay on", flush=True)
 x0 = wl.log_theta(0)
 t0 = time.perf_counter(); reps = 10
 g.Observe(x0); g.Gradient()
