@@ -163,6 +163,8 @@ def main():
                     help="candidate thetas evaluated per step in ONE launch sequence "
                          "(gogp_observe_gradient_candidates); default 8 for configs 1 and 2 (N <= 4096: one "
                          "evaluation is a latency-bound chain), 1 otherwise")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="gogp_set_option on the benchmarked handle (A/B runs), e.g. lauum_overlap=0")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300)
     args = ap.parse_args()
@@ -237,6 +239,8 @@ def main():
     g = None
     if not sharded_value:
         g = G.GP(D, simil, noise, device=local_rank, precision=prec)
+        for ov in args.option:
+            g.set_option(ov.split("=")[0], int(ov.split("=")[1]))
         # inputs resident in HBM before anything is timed
         dX = torch.from_numpy(X).to("cuda")
         dy = torch.from_numpy(y).to("cuda")
