@@ -8,10 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 FAST="--no-cpu-baseline --no-produce --candidates 1"
 python3 $R/bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 echo "bench c3 done"
+for c in 1 2 4 5; do python3 $R/bench.py --config $c > $O/bench_c$c.json 2> $O/bench_c$c.err; echo "bench c$c done"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 $R/bench.py --steps 5 --warmup 1 $FAST > $O/stats_c3.log 2>&1
 echo "stats c3 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config 2 --steps 20 --warmup 2 $FAST > $O/stats_c2.log 2>&1
-echo "stats c2 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 $R/bench.py --config 2 --candidates-per-step 1 --steps 20 --warmup 2 $FAST > $O/stats_c2.log 2>&1
+echo "stats c2 (one candidate at a time) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2k8 -- python3 $R/bench.py --config 2 --steps 10 --warmup 2 $FAST > $O/stats_c2k8.log 2>&1
+echo "stats c2 (8 candidates per launch sequence) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config 5 --nobs 32768 --steps 2 --warmup 1 $FAST > $O/stats_c5.log 2>&1
 echo "stats c5 (N=32768) done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_c3 -- python3 $R/bench.py --steps 2 --warmup 1 $FAST > $O/pmc_sq_c3.log 2>&1
