@@ -60,12 +60,12 @@ DEFAULTS = dict(OPTINP=False, MINOPT=0, ALG="lbfgs", ITERS=1000, THRESHOLD=1e-6,
                 NONORMALIZE=False, OUTOFSAMPLE=False, SEED=None)
 
 
-def _run(gp, golden_dir, **kn):
+def _run(gp, golden_dir, model=None, data="barebones.csv", ntheta=3, **kn):
     for k, v in dict(DEFAULTS, **kn).items():
         setattr(tutorial, k, v)
     out = io.StringIO()
-    with open(os.path.join(golden_dir, "barebones.csv")) as f:
-        tutorial.Evaluate(gp, gp, np.zeros(3), f, out, log=io.StringIO())
+    with open(os.path.join(golden_dir, data)) as f:
+        tutorial.Evaluate(gp, model if model is not None else gp, np.zeros(ntheta), f, out, log=io.StringIO())
     return [[float(v) for v in line.split(",")] for line in out.getvalue().strip().split("\n")], out.getvalue()
 
 
@@ -136,3 +136,105 @@ def test_evaluate_hip_matches_oracle(knobs, golden_dir):
     got, _ = _run(G.GP(1, SIMIL, NOISE), golden_dir, SEED=13, OPTINP=True, ITERS=2)
     for g, w in zip(got, want):
         assert abs(g[5] - w[5]) <= 1e-5 * max(1.0, abs(w[5])), (g, w)
+
+
+# ---- the reference's other case studies: priors through gp.Model (gp/model.go:9-28) ------------------
+def _fd(pri_factory, x, idx):
+    out = []
+    for i in idx:
+        h = 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[i] += h
+        xm[i] -= h
+        a, b = pri_factory(), pri_factory()
+        if hasattr(a, "Y"):  # the latent-output model memoises the outputs of its FIRST call
+            a.Observe(x), b.Observe(x)
+        out.append((a.Observe(xp) - b.Observe(xm)) / (2 * h))
+    return np.array(out)
+
+
+def test_case_study_priors_gradients():
+    """tutorial/hyperpriors/model/model.go and tutorial/anynoise/model/model.go restated with
+    hand-written gradients (the reference differentiates them with infergo's tape)."""
+    from gogp_amd import priors
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=6)
+    p = priors.HyperPriors()
+    v = p.Observe(x)
+    np.testing.assert_allclose(p.Gradient(), _fd(priors.HyperPriors, x, range(6)), rtol=1e-6, atol=1e-8)
+    # Normal.Logp(-1, 1, x[c1]) + ... at x = 0: closed form
+    z = priors.HyperPriors().Observe(np.zeros(6))
+    want = (-0.5 - 0.5 * np.log(2.0) ** 2 - 2 * np.log(2.0)) - 6 * 0.5 * np.log(2 * np.pi)
+    assert abs(z - want) < 1e-12 and np.isfinite(v)
+    n = 5
+    xa = np.concatenate([rng.normal(size=3), rng.uniform(0, 1, n), rng.normal(size=n)])
+    q = priors.AnyNoisePriors()
+    q.Observe(xa)                      # memoises the outputs
+    xb = xa.copy()
+    xb[3 + n:] += 0.3 * rng.normal(size=n)
+    q.Observe(xb)
+    idx = [0, 1, 2] + list(range(3 + n, 3 + 2 * n))
+
+    def factory():
+        r = priors.AnyNoisePriors()
+        r.Observe(xa)
+        return r
+
+    fd = []
+    for i in idx:
+        h = 1e-6
+        xp, xm = xb.copy(), xb.copy()
+        xp[i] += h
+        xm[i] -= h
+        fd.append((factory().Observe(xp) - factory().Observe(xm)) / (2 * h))
+    np.testing.assert_allclose(q.Gradient()[idx], fd, rtol=1e-5, atol=1e-7)
+    assert not q.Gradient()[3:3 + n].any()  # the priors do not depend on the inputs
+
+
+HYPER_SIMIL = kernel.Sum([kernel.Scaled(kernel.Matern52), kernel.Scaled(kernel.PeriodScaled(kernel.Periodic, 10.0))],
+                         order=[0, 2, 1, 3, 4])  # [c1, c2, l1, l2, p]: tutorial/hyperpriors/kernel/kernel.go:12-25
+
+
+def test_hyperpriors_case_study_on_oracle(knobs, golden_dir):
+    from gogp_amd import gp as G
+    from gogp_amd import priors
+    o = OracleGP(1, HYPER_SIMIL, kernel.ScaledNoise(0.01))
+    rows, _ = _run(o, golden_dir, model=G.Model(o, priors.HyperPriors()), data="hyperpriors.csv", ntheta=6,
+                   SEED=7, ITERS=15)
+    assert len(rows) == 44 and all(len(r) == 1 + 5 + 6 for r in rows)
+    assert all(r[5] >= r[4] - 1e-6 for r in rows[2:])  # optimisation never lowers LML + log prior
+    err = np.array([abs(r[2] - r[1]) for r in rows[24:]])
+    assert np.median(err) < 0.5  # trend + seasonality forecasts land near the data
+
+
+@pytest.mark.gpu
+def test_case_studies_hip_match_oracle(knobs, golden_dir):
+    """hyperpriors (trend + seasonality with priors) and anynoise (latent outputs, Laplacian noise,
+    full Observe form, inputs' gradient wiped: tutorial/anynoise/main.go:29-47) through the forecast
+    harness: the HIP path writes the forecasts of the oracle-backed run."""
+    from gogp_amd import gp as G
+    from gogp_amd import priors
+    noise = kernel.ScaledNoise(0.01)
+    o = OracleGP(1, HYPER_SIMIL, noise)
+    want, _ = _run(o, golden_dir, model=G.Model(o, priors.HyperPriors()), data="hyperpriors.csv", ntheta=6,
+                   SEED=21, ITERS=4)
+    g = G.GP(1, HYPER_SIMIL, noise)
+    got, _ = _run(g, golden_dir, model=G.Model(g, priors.HyperPriors()), data="hyperpriors.csv", ntheta=6,
+                  SEED=21, ITERS=4)
+    assert len(got) == len(want) == 44
+    for a, b in zip(got, want):
+        assert abs(a[4] - b[4]) <= 2e-6 * max(1.0, abs(b[4])), (a, b)   # LML + log prior at the start
+        assert abs(a[5] - b[5]) <= 1e-4 * max(1.0, abs(b[5])), (a, b)   # ... after 4 L-BFGS iterations
+        assert abs(a[2] - b[2]) <= 1e-3 * max(1.0, abs(b[2])), (a, b)   # forecast mean
+    from cases import ANYNOISE
+    _, D, simil, anoise, _, _ = ANYNOISE
+    o = OracleGP(D, simil, anoise)
+    want, _ = _run(o, golden_dir, model=priors.AnyNoiseModel(G.Model(o, priors.AnyNoisePriors())), ntheta=3,
+                   SEED=22, OPTINP=True, ITERS=3)
+    g = G.GP(D, simil, anoise)
+    got, _ = _run(g, golden_dir, model=priors.AnyNoiseModel(G.Model(g, priors.AnyNoisePriors())), ntheta=3,
+                  SEED=22, OPTINP=True, ITERS=3)
+    assert len(got) == len(want) == 20
+    for a, b in zip(got, want):
+        assert abs(a[4] - b[4]) <= 2e-6 * max(1.0, abs(b[4])), (a, b)
+        assert abs(a[5] - b[5]) <= 1e-3 * max(1.0, abs(b[5])), (a, b)
