@@ -319,6 +319,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          the exact (fp64, recomputed) Gram matrix                    (default 1)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
  *                          mat.ConditionTolerance                                   (default 16)
+ *   "graph"        1 | 0   gogp_observe_gradient_candidates up to N = 1024: capture the launch
+ *                          sequence into a hipGraph on its second identical use and replay it
+ *                          (parameters and data may change, sizes may not)              (default 1)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 
