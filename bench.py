@@ -199,9 +199,9 @@ def main():
     steps = args.steps if args.steps is not None else (3 if N > 40000 else 5 if big else 10 if N > 6000 else 50)
     warmup = args.warmup if args.warmup is not None else (1 if big else 2)
     sharded_value = wl.sharded and world > 1  # `value` = the sharded evaluation
-    # configs[4] is an fp32 configuration: single GPU -> the fp32 path (option precision = 32);
-    # the sharded evaluation computes in fp64 (no fp32 tiles yet) and says so in `dtype`
-    prec = 32 if (wl.dtype == "f32" and not sharded_value) else 64
+    # configs[4] is an fp32 configuration: option precision = 32 on one GPU and on the shards alike
+    # (float tiles and exchanges, fp32 MFMA; fp64 diagonal tiles, reductions and refinement of alpha)
+    prec = 32 if wl.dtype == "f32" else 64
     dtype = "f32" if prec == 32 else "f64"
     peak = FP32_PEAK_TFLOPS if prec == 32 else FP64_PEAK_TFLOPS
     X, y = wl.inputs()
@@ -280,7 +280,7 @@ def main():
         scaling = "weak"
     else:
         from gogp_amd.sharded import ShardedGP
-        sg = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank)
+        sg = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank, precision=prec)
 
         def step(k):
             lml = sg.Observe(wl.log_theta(k))  # the same theta on every rank: ONE evaluation
@@ -513,7 +513,7 @@ def main():
         try:
             kk = warmup + steps - 1
             if rank == 0:
-                g1 = G.GP(D, simil, noise, X=X, Y=y, device=local_rank)
+                g1 = G.GP(D, simil, noise, X=X, Y=y, device=local_rank, precision=prec)
                 lml_1 = g1.Observe(wl.log_theta(kk))
                 grad_1 = g1.Gradient()
                 g1.close()

@@ -1602,7 +1602,8 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     // blocks, vectors and all reductions stay fp64 (BASELINE config 5; DESIGN.md "fp32 path").
     // Changes the buffers: the data must be set again afterwards.
     if (value != 32 && value != 64) return fail(h, GOGP_EARG, "precision must be 32 or 64");
-    if (h->dist && value == 32) return fail(h, GOGP_EARG, "precision 32 is not available on a sharded handle");
+    if (h->dist && (int)value != h->prec)
+      return fail(h, GOGP_EARG, "precision: set it before gogp_dist_init_* (the shard's buffers are typed)");
     if ((int)value != h->prec) {
       HIPCHK(h, hipSetDevice(h->device));
       for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));

@@ -144,6 +144,8 @@ void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double
 // above the diagonal are zero-filled (the work area R of the triangular inverse).
 void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
                        int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld);
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, float *K, int64_t ld);
 void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
                              const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
                              int64_t wcols);
@@ -155,6 +157,8 @@ void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, 
 // part: nslab * npad doubles of scratch
 void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
                      const double *v, const double *y, double *part, int nslab, double *r);
+void launch_kmatvec_share(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
+                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out);
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
                   double *prior);
 
@@ -197,6 +201,10 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
                               double *out);
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const float *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out);
 
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}
@@ -219,12 +227,17 @@ void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, doub
 // helpers of the sharded evaluation (solve.hip)
 void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
                          int n);
+void launch_transpose_sq(hipStream_t s, const float *src, int64_t lds_, float *dst, int64_t ldd, int n);
 void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
                         int first, int stride);
 int64_t chunk_tdot_scratch(int64_t max_rows, int nb);  // doubles of `part` scratch
 void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
                        double *part, double *out);
+void launch_chunk_tdot(hipStream_t s, const float *chunk, int64_t rows, int nb, const double *v,
+                       double *part, double *out);
 void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out);
+void launch_chunk_alpha(hipStream_t s, const float *Ych, int mloc, int nloc, int nb, BlockMap map,
                         const double *z, double *out);
 void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
                          double *acc);

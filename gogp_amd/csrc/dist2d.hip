@@ -75,15 +75,20 @@ struct Dist2D {
   double *pack = nullptr;   // send staging of the strided column pieces
   double *scr = nullptr;    // 2 x 256 x 256 scratch of the diagonal tile
   double *yloc = nullptr;   // y at the local rows
+  double *rloc = nullptr;   // fp32 evaluation: the residual at the local rows
   double *red = nullptr;    // [z (npad) | logdet | failing pivot + 1 of every rank]
   double *ared = nullptr;   // alpha partial sums (npad)
   double *gpart = nullptr;
   double *tpart = nullptr;  // scratch of the z partial sums (chunk_tdot)
   int64_t cap_npad = 0;
   int64_t bytes = 0;
+  double *t64 = nullptr;    // fp32 evaluation: fp64 images of one diagonal tile (A, L, inverse: 3 x nb x nb)
   int ldA() const { return nloc * nb; }
-  double *lchunk(int bj) const { return Lch + (size_t)bj * mloc * nb * nb; }
-  double *ychunk(int bj) const { return Ych + (size_t)bj * mloc * nb * nb; }
+  // The matrix buffers above (A, Lch, Ych, Dinv, the panel rings, pack) hold T = double or -- on a
+  // handle with precision 32 -- float elements; typed views:
+  template <class T> T *mat(double *p) const { return reinterpret_cast<T *>(p); }
+  template <class T> T *lchunk(int bj) const { return reinterpret_cast<T *>(Lch) + (size_t)bj * mloc * nb * nb; }
+  template <class T> T *ychunk(int bj) const { return reinterpret_cast<T *>(Ych) + (size_t)bj * mloc * nb * nb; }
   int rank_of(int r, int c) const { return r * Pc + c; }
   BlockMap map() const {
     BlockMap m;
@@ -98,6 +103,19 @@ struct Dist2D {
 
 }  // namespace gogp
 
+// a transfer of `elems` elements of type T through the transport's double-typed interface (tile
+// sizes are even, so float payloads travel as half as many doubles: the transports only move bytes)
+template <class T>
+static inline XferOp xop(int peer, bool send, T *p, int64_t elems) {
+  return XferOp{peer, send, reinterpret_cast<double *>(p), elems * (int64_t)sizeof(T) / (int64_t)sizeof(double)};
+}
+template <class T>
+static inline void pack_blocks_t(hipStream_t s, T *dst, const T *src, int nblk, int64_t blk_elems, int first,
+                                 int stride) {
+  launch_pack_blocks(s, reinterpret_cast<double *>(dst), reinterpret_cast<const double *>(src), nblk,
+                     blk_elems * (int64_t)sizeof(T) / (int64_t)sizeof(double), first, stride);
+}
+
 // number of local blocks b (global index b*Pn + p) with global index <= P
 static inline int first_gt(int P, int p, int Pn) { return P >= p ? (P - p) / Pn + 1 : 0; }
 
@@ -109,8 +127,9 @@ static inline void wait(gogp_handle *h, hipStream_t s, size_t i) { (void)hipStre
 
 static void dist_free_n(Dist2D *d) {
   for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack,
-                    d->yloc, d->red, d->ared, d->gpart, d->tpart})
+                    d->yloc, d->rloc, d->red, d->ared, d->gpart, d->tpart})
     (void)hipFree(p);
+  d->rloc = nullptr;
   for (int i = 0; i < LRING; ++i) {
     (void)hipFree(d->Lrow[i]);
     (void)hipFree(d->Lcol[i]);
@@ -128,6 +147,7 @@ void gogp_dist_destroy(gogp_handle *h) {
   if (d->sc) (void)hipStreamSynchronize(d->sc);
   dist_free_n(d);
   (void)hipFree(d->scr);
+  (void)hipFree(d->t64);
   delete d->tr;
   if (d->sc) (void)hipStreamDestroy(d->sc);
   delete d;
@@ -164,10 +184,6 @@ static int dist_init_common(gogp_handle *h, int rank, int nranks, int prow, int 
     delete tr;
     return fail(h, GOGP_EARG, "dist_init: the grid must be Pr x Pc = nranks with Pr dividing Pc");
   }
-  if (h->prec != 64) {
-    delete tr;
-    return fail(h, GOGP_EARG, "dist_init: a sharded handle computes in fp64 (precision 32 is single-GPU)");
-  }
   if (h->dist) gogp_dist_destroy(h);
   Dist2D *d = new Dist2D();
   d->rank = rank;
@@ -179,6 +195,7 @@ static int dist_init_common(gogp_handle *h, int rank, int nranks, int prow, int 
   d->tr = tr;
   hipError_t e = hipStreamCreateWithFlags(&d->sc, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&d->scr, (size_t)2 * PANEL * PANEL * sizeof(double));
+  if (e == hipSuccess && h->prec == 32) e = hipMalloc(&d->t64, (size_t)3 * d->nb * d->nb * sizeof(double));
   h->dist = d;
   if (e != hipSuccess) {
     gogp_dist_destroy(h);
@@ -234,7 +251,7 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
   if (npad > d->cap_npad) {
     // the unsharded N x N buffers are never allocated on a sharded handle
     for (double **p : {&h->dX, &h->dy, &h->bufA, &h->bufL, &h->bufY, &h->Dinv, &h->z, &h->w, &h->alpha,
-                       &h->gpart}) {
+                       &h->gpart, &h->rw, &h->rz, &h->rd, &h->rpart}) {
       (void)hipFree(*p);
       *p = nullptr;
     }
@@ -248,20 +265,29 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
     HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
     d->bytes = (int64_t)((size_t)npad * (h->D + 3) * sizeof(double));
-    DMALLOC(d->A, mrows * ncols);
-    DMALLOC(d->Lch, mrows * ncols);
-    DMALLOC(d->Ych, mrows * ncols);
-    DMALLOC(d->Dinv, (size_t)d->NB * nb2);
+    // matrix buffers: float elements on a precision-32 handle (counts in doubles, rounded up)
+    const size_t es = h->esz();
+    auto dbl = [&](size_t elems) { return (elems * es + sizeof(double) - 1) / sizeof(double); };
+    DMALLOC(d->A, dbl(mrows * ncols));
+    DMALLOC(d->Lch, dbl(mrows * ncols));
+    DMALLOC(d->Ych, dbl(mrows * ncols));
+    DMALLOC(d->Dinv, dbl((size_t)d->NB * nb2));
     for (int i = 0; i < LRING; ++i) {
-      DMALLOC(d->Lrow[i], mrows * d->nb);
-      DMALLOC(d->Lcol[i], ncols * d->nb);
+      DMALLOC(d->Lrow[i], dbl(mrows * d->nb));
+      DMALLOC(d->Lcol[i], dbl(ncols * d->nb));
     }
     for (int i = 0; i < 2; ++i) {
-      DMALLOC(d->Yrow[i], mrows * d->nb);
-      DMALLOC(d->Ycol[i], ncols * d->nb);
+      DMALLOC(d->Yrow[i], dbl(mrows * d->nb));
+      DMALLOC(d->Ycol[i], dbl(ncols * d->nb));
     }
-    DMALLOC(d->pack, (size_t)(d->Pc / d->Pr) * ncols * d->nb);
+    DMALLOC(d->pack, dbl((size_t)(d->Pc / d->Pr) * ncols * d->nb));
     DMALLOC(d->yloc, mrows);
+    if (h->prec == 32) {  // refinement of alpha: residual scratch
+      DMALLOC(d->rloc, mrows);
+      HIPCHK(h, hipMalloc(&h->rw, (size_t)npad * sizeof(double)));
+      HIPCHK(h, hipMalloc(&h->rpart, (size_t)REFINE_SLABS * npad * sizeof(double)));
+      d->bytes += (int64_t)((size_t)(1 + REFINE_SLABS) * npad * sizeof(double));
+    }
     DMALLOC(d->red, (size_t)npad + 1 + d->nranks);
     DMALLOC(d->ared, (size_t)npad);
     DMALLOC(d->gpart, (size_t)grad_reduce_blocks_local((int64_t)mrows, (int64_t)ncols) * NACC);
@@ -271,6 +297,15 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
   return GOGP_OK;
 }
 
+__global__ void residual_from_kernel(double *__restrict__ kv, const double *__restrict__ y, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) kv[i] = y[i] - kv[i];
+}
+static void launch_residual_from(hipStream_t s, double *kv, const double *y, int64_t count) {  // kv := y - kv
+  if (count <= 0) return;
+  hipLaunchKernelGGL(residual_from_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, kv, y, (long)count);
+}
+
 __global__ void gather_rows_kernel(const double *__restrict__ y, double *__restrict__ yloc, long rows,
                                    BlockMap map) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,22 +313,20 @@ __global__ void gather_rows_kernel(const double *__restrict__ y, double *__restr
 }
 
 // ---- the diagonal tile: factor + inverse of one nb x nb block on the chain stream -----------
-static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d, int bj_d) {
-  const int nb = d->nb, ldA = d->ldA();
-  const size_t nb2 = (size_t)nb * nb;
-  double *Ablk = d->A + (size_t)bi_d * nb * ldA + (size_t)bj_d * nb;
-  double *Lblk = d->lchunk(bj_d) + (size_t)bi_d * nb2;
-  double *Dv = d->Dinv + (size_t)P * nb2;
-  const int64_t row0 = (int64_t)P * nb;
+// Always fp64 (as the 256-blocks of the single-GPU path): Ablk (lda) in, Lblk (ld nb) and its dense
+// inverse Dv (ld nb) out; the log-determinant is accumulated from the fp64 factor.
+static void diag_tile64(gogp_handle *h, Dist2D *d, hipStream_t sp, double *Ablk, int lda, double *Lblk,
+                        double *Dv, int64_t row0) {
+  const int nb = d->nb;
   GemmProfile *pf = &h->prof;
   // L_PP = [[L00, 0], [L10, L11]];  inv = [[X00, 0], [-X11 L10 X00, X11]]
-  launch_diag256_ld512(sp, Ablk, ldA, Lblk, nb, Dv, row0, h->n, h->info);
+  launch_diag256_ld512(sp, Ablk, lda, Lblk, nb, Dv, row0, h->n, h->info);
   double *L10 = Lblk + (size_t)PANEL * nb;
-  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, Ablk + (size_t)PANEL * ldA, ldA, Dv, nb, 0.0, L10, nb,
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, Ablk + (size_t)PANEL * lda, lda, Dv, nb, 0.0, L10, nb,
                   pf);
   launch_dgemm_nt(sp, GEMM_LOWER, 2, 2, PANEL, -1.0, L10, nb, L10, nb, 1.0,
-                  Ablk + (size_t)PANEL * ldA + PANEL, ldA, pf);
-  launch_diag256_ld512(sp, Ablk + (size_t)PANEL * ldA + PANEL, ldA, Lblk + (size_t)PANEL * nb + PANEL, nb,
+                  Ablk + (size_t)PANEL * lda + PANEL, lda, pf);
+  launch_diag256_ld512(sp, Ablk + (size_t)PANEL * lda + PANEL, lda, Lblk + (size_t)PANEL * nb + PANEL, nb,
                        Dv + (size_t)PANEL * nb + PANEL, row0 + PANEL, h->n, h->info);
   launch_zero_block(sp, Dv + PANEL, nb, PANEL, PANEL);
   launch_zero_block(sp, Lblk + PANEL, nb, PANEL, PANEL);
@@ -305,6 +338,26 @@ static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d
   launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, -1.0, Dv + (size_t)PANEL * nb + PANEL, nb, WT, PANEL, 0.0,
                   Dv + (size_t)PANEL * nb, nb, pf);
   launch_logdet_block(sp, Lblk, nb, row0, h->n, nb, d->red + h->npad);
+}
+static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d, int bj_d, double) {
+  const int nb = d->nb, ldA = d->ldA();
+  const size_t nb2 = (size_t)nb * nb;
+  diag_tile64(h, d, sp, d->A + (size_t)bi_d * nb * ldA + (size_t)bj_d * nb, ldA,
+              d->lchunk<double>(bj_d) + (size_t)bi_d * nb2, d->Dinv + (size_t)P * nb2, (int64_t)P * nb);
+}
+// fp32 evaluation: the tile is widened into fp64 scratch, factored and inverted there, and the
+// factor and the inverse are rounded to float once (api.hip: diag_block does the same per 256-block)
+static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d, int bj_d, float) {
+  const int nb = d->nb, ldA = d->ldA();
+  const size_t nb2 = (size_t)nb * nb;
+  float *Ablk = d->mat<float>(d->A) + (size_t)bi_d * nb * ldA + (size_t)bj_d * nb;
+  float *Lblk = d->lchunk<float>(bj_d) + (size_t)bi_d * nb2;
+  float *Dv = d->mat<float>(d->Dinv) + (size_t)P * nb2;
+  double *A64 = d->t64, *L64 = d->t64 + nb2, *D64 = d->t64 + 2 * nb2;
+  launch_convert_block(sp, Ablk, ldA, A64, nb, nb, nb);
+  diag_tile64(h, d, sp, A64, nb, L64, D64, (int64_t)P * nb);
+  launch_convert_block(sp, L64, nb, Lblk, nb, nb, nb);
+  launch_convert_block(sp, D64, nb, Dv, nb, nb, nb);
 }
 
 #define TRCHK(call)                            \
@@ -318,8 +371,10 @@ static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d
   } while (0)
 
 // ---- one sharded evaluation: Gram + Cholesky + triangular inverse (+ K^-1) -------------------
-int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
+template <class T>
+static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
   Dist2D *d = h->dist;
+  T *const A = d->mat<T>(d->A), *const Dinv = d->mat<T>(d->Dinv), *const packb = d->mat<T>(d->pack);
   const int nb = d->nb, tpb = d->tpb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc;
   const int NB = d->NB, mloc = d->mloc, nloc = d->nloc, ldA = d->ldA();
   const int q = Pc / Pr;
@@ -343,7 +398,7 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
                      d->yloc, lrows, d->map());
   // every rank builds its own tiles of K (X is replicated): no communication for the O(N^2) step;
   // the strictly upper blocks are zero-filled (R)
-  launch_gram_local(s, h->devP, h->D, h->dX, h->n, (int64_t)mloc * nb, (int64_t)nloc * nb, d->map(), d->A,
+  launch_gram_local(s, h->devP, h->D, h->dX, h->n, (int64_t)mloc * nb, (int64_t)nloc * nb, d->map(), A,
                     ldA);
   rec(h, EV_GRAM, s);
   for (hipStream_t qs : {sp, st, s2, sc}) wait(h, qs, EV_GRAM);
@@ -358,13 +413,13 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     const bool in_col = (pc == kc), in_row = (pr == kr), is_diag = in_col && in_row;
     const int lslot = P % LRING;
     const int diag_rank = d->rank_of(kr, kc);
-    double *Dv = d->Dinv + (size_t)P * nb2;
+    T *Dv = Dinv + (size_t)P * nb2;
     const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);  // I hold tiles of block column P+1
 
     // ---- 1. diagonal tile -----------------------------------------------------------------
     if (in_col && P >= 2) wait(h, sp, E(P - 2, EUPD));  // bulk update of step P-2 touched column P
     if (is_diag) {
-      diag_tile(h, d, sp, P, bi_d, bj_d);
+      diag_tile(h, d, sp, P, bi_d, bj_d, T());
       rec(h, E(P, EDIAG), sp);
       wait(h, sc, E(P, EDIAG));
     }
@@ -372,9 +427,9 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     if (d->nranks > 1) {
       if (is_diag) {
         for (int r = 0; r < d->nranks; ++r)
-          if (r != d->rank) ops.push_back({r, true, Dv, (int64_t)nb2});
+          if (r != d->rank) ops.push_back(xop<T>(r, true, Dv, (int64_t)nb2));
       } else {
-        ops.push_back({diag_rank, false, Dv, (int64_t)nb2});
+        ops.push_back(xop<T>(diag_rank, false, Dv, (int64_t)nb2));
       }
       TRCHK(d->tr->group(sc, ops, &e_));
     }
@@ -384,46 +439,46 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     if (in_col) {
       wait(h, sp, E(P, ED));
       if (bi0 < mloc)
-        launch_dgemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, 1.0,
-                        d->A + (size_t)bi0 * nb * ldA + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
-                        d->lchunk(bj_d) + (size_t)bi0 * nb2, nb, pf);
+        launch_gemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, 1.0,
+                        A + (size_t)bi0 * nb * ldA + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
+                        d->lchunk<T>(bj_d) + (size_t)bi0 * nb2, nb, pf);
       rec(h, E(P, EPANEL), sp);
       wait(h, sc, E(P, EPANEL));
     }
 
     // ---- 3. exchange of the L panel -----------------------------------------------------------
-    double *Lrow = in_col ? d->lchunk(bj_d) : d->Lrow[lslot];
+    T *Lrow = in_col ? d->lchunk<T>(bj_d) : d->mat<T>(d->Lrow[lslot]);
     // square grid, diagonal rank: my tile columns are my tile rows -- no copy, the same buffer
     const bool alias = (q == 1 && pc % Pr == pr);
-    double *Lcol = alias ? Lrow : d->Lcol[lslot];
+    T *Lcol = alias ? Lrow : d->mat<T>(d->Lcol[lslot]);
     if (P >= LRING)  // the panel buffers of step P - LRING are still being read by its updates
       for (int k : {EUPD, ELA, ERUPD, ERLA}) wait(h, sc, E(P - LRING, k));
     ops.clear();
     const int64_t cnt_row = (int64_t)(mloc - bi0) * (int64_t)nb2;
     if (in_col) {
       for (int c = 0; c < Pc; ++c)
-        if (c != kc) ops.push_back({d->rank_of(pr, c), true, Lrow + (size_t)bi0 * nb2, cnt_row});
+        if (c != kc) ops.push_back(xop<T>(d->rank_of(pr, c), true, Lrow + (size_t)bi0 * nb2, cnt_row));
       if (Pr > 1) {
         int idx = 0;
         for (int pc2 = pr; pc2 < Pc; pc2 += Pr, ++idx) {  // receivers' grid columns served by me
           const int bj02 = first_gt(P, pc2, Pc);
           const int nblk = nloc - bj02;
           if (nblk <= 0) continue;
-          double *pk = d->pack + (size_t)idx * nloc * nb2;
-          launch_pack_blocks(sc, pk, Lrow, nblk, (int64_t)nb2, bj02 * q + (pc2 - pr) / Pr, q);
+          T *pk = packb + (size_t)idx * nloc * nb2;
+          pack_blocks_t<T>(sc, pk, Lrow, nblk, (int64_t)nb2, bj02 * q + (pc2 - pr) / Pr, q);
           for (int r2 = 0; r2 < Pr; ++r2)
-            if (r2 != pr) ops.push_back({d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2});
+            if (r2 != pr) ops.push_back(xop<T>(d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2));
         }
       }
     } else {
-      ops.push_back({d->rank_of(pr, kc), false, Lrow + (size_t)bi0 * nb2, cnt_row});
+      ops.push_back(xop<T>(d->rank_of(pr, kc), false, Lrow + (size_t)bi0 * nb2, cnt_row));
     }
     const int src_r = pc % Pr;  // grid row of the rank holding the tiles of my tile columns
     if (src_r != pr && nloc - bj0 > 0)
-      ops.push_back({d->rank_of(src_r, kc), false, Lcol + (size_t)bj0 * nb2, (int64_t)(nloc - bj0) * (int64_t)nb2});
+      ops.push_back(xop<T>(d->rank_of(src_r, kc), false, Lcol + (size_t)bj0 * nb2, (int64_t)(nloc - bj0) * (int64_t)nb2));
     TRCHK(d->tr->group(sc, ops, &e_));
     if (src_r == pr && !alias)
-      launch_pack_blocks(sc, Lcol + (size_t)bj0 * nb2, Lrow, nloc - bj0, (int64_t)nb2,
+      pack_blocks_t<T>(sc, Lcol + (size_t)bj0 * nb2, Lrow, nloc - bj0, (int64_t)nb2,
                          bj0 * q + (pc - pr) / Pr, q);
     rec(h, E(P, EL), sc);
 
@@ -443,8 +498,8 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
         wait(h, sp, E(P, EL));
         if (P >= 1) wait(h, sp, E(P - 1, EUPD));  // bulk update of step P-1 touched it
         gg.cblk0 = bj0;
-        launch_dgemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, -1.0, Lrow + (size_t)bi0 * nb2, nb,
-                        Lcol + (size_t)bj0 * nb2, nb, 1.0, d->A + (size_t)bi0 * nb * ldA + (size_t)bj0 * nb,
+        launch_gemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, -1.0, Lrow + (size_t)bi0 * nb2, nb,
+                        Lcol + (size_t)bj0 * nb2, nb, 1.0, A + (size_t)bi0 * nb * ldA + (size_t)bj0 * nb,
                         ldA, pf, &gg);
         cst = bj0 + 1;
       }
@@ -452,9 +507,9 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
       wait(h, s, E(P, EL));
       if (bi0 < mloc && cst < nloc) {
         gg.cblk0 = cst;
-        launch_dgemm_nt(s, GEMM_RECT, (mloc - bi0) * tpb, (nloc - cst) * tpb, nb, -1.0,
+        launch_gemm_nt(s, GEMM_RECT, (mloc - bi0) * tpb, (nloc - cst) * tpb, nb, -1.0,
                         Lrow + (size_t)bi0 * nb2, nb, Lcol + (size_t)cst * nb2, nb, 1.0,
-                        d->A + (size_t)bi0 * nb * ldA + (size_t)cst * nb, ldA, pf, &gg);
+                        A + (size_t)bi0 * nb * ldA + (size_t)cst * nb, ldA, pf, &gg);
       }
       rec(h, E(P, EUPD), s);
     }
@@ -469,11 +524,11 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
     const int bj0 = first_gt(P, pc, Pc);
     const bool in_col = (pc == kc), in_row = (pr == kr), is_diag = in_col && in_row;
     const int slot = P & 1, lslot = P % LRING;
-    double *Dv = d->Dinv + (size_t)P * nb2;
+    T *Dv = Dinv + (size_t)P * nb2;
     const bool next_mine = (P + 1 < NB) && (pc == (P + 1) % Pc);
     const int src_r = pc % Pr;
     const bool alias = (q == 1 && src_r == pr);
-    double *Lcol = alias ? (in_col ? d->lchunk(bj_d) : d->Lrow[lslot]) : d->Lcol[lslot];
+    T *Lcol = alias ? (in_col ? d->lchunk<T>(bj_d) : d->mat<T>(d->Lrow[lslot])) : d->mat<T>(d->Lcol[lslot]);
 
     // ---- 5. column panel P of Y = L^-T -----------------------------------------------------------
     const int bim = in_row ? bi0 - 1 : bi0;  // local row blocks with global index < P
@@ -481,43 +536,43 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
       wait(h, st, E(P, ED));
       if (P >= 2) wait(h, st, E(P - 2, ERUPD));  // bulk R update of step P-2 touched column P
       if (bim > 0)
-        launch_dgemm_nt(st, GEMM_RECT, bim * tpb, tpb, nb, 1.0, d->A + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
-                        d->ychunk(bj_d), nb, pf);
-      if (is_diag) launch_transpose_sq(st, Dv, nb, d->ychunk(bj_d) + (size_t)bi_d * nb2, nb, nb);
+        launch_gemm_nt(st, GEMM_RECT, bim * tpb, tpb, nb, 1.0, A + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
+                        d->ychunk<T>(bj_d), nb, pf);
+      if (is_diag) launch_transpose_sq(st, Dv, nb, d->ychunk<T>(bj_d) + (size_t)bi_d * nb2, nb, nb);
       if (bi0 > 0)  // z_P += sum_I Y[I, P]^T y_I over my tile rows
-        launch_chunk_tdot(st, d->ychunk(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->tpart, d->red + (size_t)P * nb);
+        launch_chunk_tdot(st, d->ychunk<T>(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->tpart, d->red + (size_t)P * nb);
       rec(h, E(P, EYCH), st);
       wait(h, sc, E(P, EYCH));
     }
 
     // ---- 6. exchange of the Y panel ------------------------------------------------------------
-    double *Yrow = in_col ? d->ychunk(bj_d) : d->Yrow[slot];
-    double *Ycol = alias ? Yrow : d->Ycol[slot];
+    T *Yrow = in_col ? d->ychunk<T>(bj_d) : d->mat<T>(d->Yrow[slot]);
+    T *Ycol = alias ? Yrow : d->mat<T>(d->Ycol[slot]);
     if (P >= 2)  // the Y panel buffers of step P-2 are still being read by its updates
       for (int k : {ERUPD, ERLA}) wait(h, sc, E(P - 2, k));
     ops.clear();
     const int64_t cnt_yrow = (int64_t)bi0 * (int64_t)nb2;
     if (in_col) {
       for (int c = 0; c < Pc; ++c)
-        if (c != kc) ops.push_back({d->rank_of(pr, c), true, Yrow, cnt_yrow});
+        if (c != kc) ops.push_back(xop<T>(d->rank_of(pr, c), true, Yrow, cnt_yrow));
       if (Pr > 1) {
         int idx = 0;
         for (int pc2 = pr; pc2 < Pc; pc2 += Pr, ++idx) {
           const int nblk = first_gt(P, pc2, Pc);  // tile columns <= P of grid column pc2
           if (nblk <= 0) continue;
-          double *pk = d->pack + (size_t)idx * nloc * nb2;
-          launch_pack_blocks(sc, pk, Yrow, nblk, (int64_t)nb2, (pc2 - pr) / Pr, q);
+          T *pk = packb + (size_t)idx * nloc * nb2;
+          pack_blocks_t<T>(sc, pk, Yrow, nblk, (int64_t)nb2, (pc2 - pr) / Pr, q);
           for (int r2 = 0; r2 < Pr; ++r2)
-            if (r2 != pr) ops.push_back({d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2});
+            if (r2 != pr) ops.push_back(xop<T>(d->rank_of(r2, pc2), true, pk, (int64_t)nblk * (int64_t)nb2));
         }
       }
     } else {
-      ops.push_back({d->rank_of(pr, kc), false, Yrow, cnt_yrow});
+      ops.push_back(xop<T>(d->rank_of(pr, kc), false, Yrow, cnt_yrow));
     }
     if (src_r != pr && bj0 > 0)
-      ops.push_back({d->rank_of(src_r, kc), false, Ycol, (int64_t)bj0 * (int64_t)nb2});
+      ops.push_back(xop<T>(d->rank_of(src_r, kc), false, Ycol, (int64_t)bj0 * (int64_t)nb2));
     TRCHK(d->tr->group(sc, ops, &e_));
-    if (src_r == pr && !alias) launch_pack_blocks(sc, Ycol, Yrow, bj0, (int64_t)nb2, (pc - pr) / Pr, q);
+    if (src_r == pr && !alias) pack_blocks_t<T>(sc, Ycol, Yrow, bj0, (int64_t)nb2, (pc - pr) / Pr, q);
     rec(h, E(P, EY), sc);
 
     // ---- 7. R update (rows <= P, columns > P) and the rank-nb update of K^-1 -----------------------
@@ -527,16 +582,16 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
         wait(h, st, E(P, EY));
         wait(h, st, E(P, EL));
         if (P >= 1) wait(h, st, E(P - 1, ERUPD));
-        launch_dgemm_nt(st, GEMM_RECT, bi0 * tpb, tpb, nb, -1.0, Yrow, nb, Lcol + (size_t)bj0 * nb2, nb, 1.0,
-                        d->A + (size_t)bj0 * nb, ldA, pf);
+        launch_gemm_nt(st, GEMM_RECT, bi0 * tpb, tpb, nb, -1.0, Yrow, nb, Lcol + (size_t)bj0 * nb2, nb, 1.0,
+                        A + (size_t)bj0 * nb, ldA, pf);
         cst = bj0 + 1;
       }
       rec(h, E(P, ERLA), st);
       wait(h, s2, E(P, EY));
       wait(h, s2, E(P, EL));
       if (bi0 > 0 && cst < nloc)
-        launch_dgemm_nt(s2, GEMM_RECT, bi0 * tpb, (nloc - cst) * tpb, nb, -1.0, Yrow, nb,
-                        Lcol + (size_t)cst * nb2, nb, 1.0, d->A + (size_t)cst * nb, ldA, pf);
+        launch_gemm_nt(s2, GEMM_RECT, bi0 * tpb, (nloc - cst) * tpb, nb, -1.0, Yrow, nb,
+                        Lcol + (size_t)cst * nb2, nb, 1.0, A + (size_t)cst * nb, ldA, pf);
       if (want_kinv && bi0 > 0 && bj0 > 0) {
         GemmGrid gk;
         gk.rule = 2;
@@ -548,7 +603,7 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
         gk.rblk0 = 0;
         gk.cblk0 = 0;
         gk.beta0 = P;
-        launch_dgemm_nt(s2, GEMM_RECT, bi0 * tpb, bj0 * tpb, nb, 1.0, Yrow, nb, Ycol, nb, 1.0, d->A, ldA, pf,
+        launch_gemm_nt(s2, GEMM_RECT, bi0 * tpb, bj0 * tpb, nb, 1.0, Yrow, nb, Ycol, nb, 1.0, A, ldA, pf,
                         &gk);
       }
       rec(h, E(P, ERUPD), s2);
@@ -577,12 +632,41 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
   HIPCHK(h, hipMemcpyAsync(h->z, d->red, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sc));
   launch_sumsq_info(sc, h->z, h->n, nullptr, h->scalars);
   // alpha = Y z: partial sums over the local chunks, second all-reduce
-  launch_chunk_alpha(sc, d->Ych, mloc, nloc, nb, d->map(), h->z, d->ared);
+  launch_chunk_alpha(sc, d->mat<T>(d->Ych), mloc, nloc, nb, d->map(), h->z, d->ared);
   TRCHK(d->tr->allreduce(sc, d->ared, npad, &e_));
   HIPCHK(h, hipMemcpyAsync(h->alpha, d->ared, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sc));
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, sizeof(double), hipMemcpyDeviceToHost, sc));
   HIPCHK(h, hipMemcpyAsync(h->hscal + 1, d->red + npad, (size_t)(1 + d->nranks) * sizeof(double),
                            hipMemcpyDeviceToHost, sc));
+  if (sizeof(T) == 4) {
+    // fp32 tiles: `refine_steps` steps of iterative refinement of alpha against the EXACT Gram matrix
+    // (api.hip: factorize_t; DESIGN.md "fp32 path"), sharded: every rank multiplies its share of the
+    // columns of K (recomputed in fp64 on the fly) with alpha, one all-reduce gives K alpha; the
+    // correction Y (Y^T r) uses the local chunks of Y like z and alpha above (two all-reduces).  The
+    // quadratic term of the LML is y^T alpha of the refined alpha.
+    for (int it = 0; it < h->refine_steps; ++it) {
+      launch_kmatvec_share(sc, h->devP, h->D, h->dX, h->n, npad, h->alpha, d->rank, d->nranks, h->rpart,
+                           REFINE_SLABS, h->rw);
+      TRCHK(d->tr->allreduce(sc, h->rw, npad, &e_));
+      launch_residual_from(sc, h->rw, h->dy, npad);  // rw := y - K alpha, then its local rows
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((lrows + 255) / 256)), dim3(256), 0, sc, h->rw,
+                         d->rloc, lrows, d->map());
+      // both reduction vectors start from zero: every rank fills only its own panels / rows
+      HIPCHK(h, hipMemsetAsync(d->red, 0, (size_t)npad * sizeof(double), sc));
+      HIPCHK(h, hipMemsetAsync(d->ared, 0, (size_t)npad * sizeof(double), sc));
+      for (int bj = 0; bj < nloc; ++bj) {
+        const int P = bj * Pc + pc;
+        const int bi0 = first_gt(P, pr, Pr);
+        if (bi0 > 0)
+          launch_chunk_tdot(sc, d->ychunk<T>(bj), (int64_t)bi0 * nb, nb, d->rloc, d->tpart, d->red + (size_t)P * nb);
+      }
+      TRCHK(d->tr->allreduce(sc, d->red, npad, &e_));
+      launch_chunk_alpha(sc, d->mat<T>(d->Ych), mloc, nloc, nb, d->map(), d->red, d->ared);
+      TRCHK(d->tr->allreduce(sc, d->ared, npad, &e_));
+      launch_axpy(sc, h->alpha, d->ared, npad);
+    }
+    launch_dot(sc, h->dy, h->alpha, h->n, h->scalars);
+  }
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, sizeof(double), hipMemcpyDeviceToHost, sc));
   HIPCHK(h, hipStreamSynchronize(sc));
   HIPCHK(h, hipGetLastError());
   const double zz = h->hscal[0], logdet = h->hscal[1];
@@ -607,14 +691,22 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
   return GOGP_OK;
 }
 
+int gogp_dist_factorize(gogp_handle *h, bool want_kinv) {
+  return h->prec == 32 ? dist_factorize_t<float>(h, want_kinv) : dist_factorize_t<double>(h, want_kinv);
+}
+
 // ---- gradient: fused reduction over the local tiles of K^-1, one all-reduce ------------------------
 int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
   Dist2D *d = h->dist;
   if (!h->have_kinv) return fail(h, GOGP_ESTATE, "Gradient: K^-1 was not formed (Absorb?)");
   hipStream_t s2 = h->s2, sc = d->sc;
   // the last rank-nb updates of K^-1 run on s2; alpha is final (host-synchronised)
-  launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->A, d->ldA(), h->n,
-                           (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout);
+  if (h->prec == 32)
+    launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->mat<float>(d->A), d->ldA(), h->n,
+                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout);
+  else
+    launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->A, d->ldA(), h->n,
+                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout);
   rec(h, EV_ALPHA, s2);
   wait(h, sc, EV_ALPHA);
   TRCHK(d->tr->allreduce(sc, h->gout, NACC, &e_));
@@ -625,17 +717,19 @@ int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
 }
 
 // ---- gp.GP.L of a sharded handle: gather the tiles (collective; every rank gets the whole factor) ---
-__global__ void scatter_tile_kernel(const double *__restrict__ src, int nb, double *__restrict__ dst, long n,
+template <class T>
+__global__ void scatter_tile_kernel(const T *__restrict__ src, int nb, double *__restrict__ dst, long n,
                                     long row0, long col0, int diag) {
   const long r = row0 + blockIdx.x;
   if (r >= n) return;
   for (int c = threadIdx.x; c < nb; c += blockDim.x) {
     const long gc = col0 + c;
-    if (gc < n && (!diag || gc <= r)) dst[r * n + gc] = src[(long)blockIdx.x * nb + c];
+    if (gc < n && (!diag || gc <= r)) dst[r * n + gc] = (double)src[(long)blockIdx.x * nb + c];
   }
 }
 
-int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
+template <class T>
+static int dist_get_factor_t(gogp_handle *h, double *Lout) {
   Dist2D *d = h->dist;
   const int nb = d->nb;
   const int64_t n = h->n;
@@ -648,8 +742,8 @@ int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
     for (int bi = 0; bi < d->mloc; ++bi) {
       const int gI = bi * d->Pr + d->pr;
       if (gI < gP || (int64_t)gI * nb >= n || (int64_t)gP * nb >= n) continue;
-      hipLaunchKernelGGL(scatter_tile_kernel, dim3(nb), dim3(256), 0, d->sc,
-                         d->lchunk(bj) + (size_t)bi * nb * nb, nb, tmp, (long)n, (long)gI * nb, (long)gP * nb,
+      hipLaunchKernelGGL(scatter_tile_kernel<T>, dim3(nb), dim3(256), 0, d->sc,
+                         d->lchunk<T>(bj) + (size_t)bi * nb * nb, nb, tmp, (long)n, (long)gI * nb, (long)gP * nb,
                          gI == gP ? 1 : 0);
     }
   }
@@ -666,6 +760,10 @@ int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
   }
   HIPCHK(h, e);
   return GOGP_OK;
+}
+
+int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
+  return h->prec == 32 ? dist_get_factor_t<float>(h, Lout) : dist_get_factor_t<double>(h, Lout);
 }
 
 // ---- Produce on a sharded handle -----------------------------------------------------------------
@@ -686,9 +784,10 @@ __global__ void gather_x_kernel(const double *__restrict__ X, const double *__re
 }
 
 // dst (cols x rows, ldd) = src (rows x cols, lds)^T; rows, cols multiples of 32
-__global__ __launch_bounds__(256) void transpose_rect_kernel(const double *__restrict__ src, long lds_,
-                                                             double *__restrict__ dst, long ldd, int ntc) {
-  __shared__ double tile[32][33];
+template <class T>
+__global__ __launch_bounds__(256) void transpose_rect_kernel(const T *__restrict__ src, long lds_,
+                                                             T *__restrict__ dst, long ldd, int ntc) {
+  __shared__ T tile[32][33];
   const int bx = blockIdx.x % ntc, by = blockIdx.x / ntc;  // bx: column tile, by: row tile of src
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -698,7 +797,8 @@ __global__ __launch_bounds__(256) void transpose_rect_kernel(const double *__res
   for (int r = 0; r < 32; r += 8) dst[(long)(bx * 32 + ty + r) * ldd + by * 32 + tx] = tile[tx][ty + r];
 }
 
-__global__ void add_inplace_kernel(double *__restrict__ a, const double *__restrict__ b, long count) {
+template <class T>
+__global__ void add_inplace_kernel(T *__restrict__ a, const T *__restrict__ b, long count) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
     a[i] += b[i];
 }
@@ -708,7 +808,8 @@ __global__ void scale_kernel(double *__restrict__ a, double f, long count) {
   if (i < count) a[i] *= f;
 }
 
-int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
+template <class T>
+static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
   Dist2D *d = h->dist;
   if (!h->trtri_done) return fail(h, GOGP_ESTATE, "Produce: no factorisation");
   const int nb = d->nb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc, mloc = d->mloc, nloc = d->nloc;
@@ -716,14 +817,15 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
   const int64_t lrows = (int64_t)mloc * nb, lcols = (int64_t)nloc * nb;
   hipStream_t s = h->s, sc = d->sc;
   for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, sc}) HIPCHK(h, hipStreamSynchronize(qs));
-  double *dZ = nullptr, *Xloc = nullptr, *aloc = nullptr, *Ks = nullptr, *Yt = nullptr, *Vt = nullptr,
-         *Vr = nullptr, *vec = nullptr;
+  double *dZ = nullptr, *Xloc = nullptr, *aloc = nullptr, *vec = nullptr;
+  T *Ks = nullptr, *Yt = nullptr, *Vt = nullptr, *Vr = nullptr;  // matrices in the handle's element type
   auto cleanup = [&]() {
-    for (double *p : {dZ, Xloc, aloc, Ks, Yt, Vt, Vr, vec}) (void)hipFree(p);
+    for (double *p : {dZ, Xloc, aloc, vec}) (void)hipFree(p);
+    for (T *p : {Ks, Yt, Vt, Vr}) (void)hipFree(p);
   };
 #define PMALLOC(ptr, count)                                                              \
   do {                                                                                   \
-    if (hipMalloc(&(ptr), (size_t)(count) * sizeof(double) + 16) != hipSuccess) {         \
+    if (hipMalloc(&(ptr), (size_t)(count) * sizeof(*(ptr)) + 16) != hipSuccess) {        \
       cleanup();                                                                         \
       (void)hipGetLastError();                                                           \
       return fail(h, GOGP_ENOMEM, "Produce: out of device memory");                      \
@@ -739,7 +841,7 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
   PMALLOC(vec, 4 * mpad);
   double *prior = vec, *red2 = vec + mpad /* [mu | q] */, *dsig = vec + 3 * mpad;
   hipError_t e = hipMemcpyAsync(dZ, Z, (size_t)m * h->D * sizeof(double), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemsetAsync(Vt, 0, (size_t)mpad * lcols * sizeof(double), s);
+  if (e == hipSuccess) e = hipMemsetAsync(Vt, 0, (size_t)mpad * lcols * sizeof(T), s);
   if (e == hipSuccess) e = hipMemsetAsync(red2, 0, (size_t)2 * mpad * sizeof(double), s);
   if (e != hipSuccess) {
     cleanup();
@@ -770,10 +872,10 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
     const int bi0 = first_gt(P, pr, Pr);
     if (bi0 <= 0) continue;
     const int64_t K = (int64_t)bi0 * nb;
-    hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)((K / 32) * (nb / 32))), dim3(256), 0, s,
-                       d->ychunk(bj), (long)nb, Yt, (long)K, nb / 32);
-    launch_dgemm_nt(s, GEMM_RECT, mt, d->tpb, K, 1.0, Ks, lrows, Yt, K, 0.0, Vt + (size_t)bj * nb, lcols,
-                    nullptr);
+    hipLaunchKernelGGL(transpose_rect_kernel<T>, dim3((unsigned)((K / 32) * (nb / 32))), dim3(256), 0, s,
+                       d->ychunk<T>(bj), (long)nb, Yt, (long)K, nb / 32);
+    launch_gemm_nt(s, GEMM_RECT, mt, d->tpb, K, 1.0, Ks, lrows, Yt, K, 0.0, Vt + (size_t)bj * nb, lcols,
+                   nullptr);
   }
   // add the partial sums of the other ranks of my process column
   std::vector<XferOp> ops;
@@ -783,8 +885,8 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
     int k = 0;
     for (int r2 = 0; r2 < Pr; ++r2) {
       if (r2 == pr) continue;
-      ops.push_back({d->rank_of(r2, pc), true, Vt, mpad * lcols});
-      ops.push_back({d->rank_of(r2, pc), false, Vr + (size_t)k * mpad * lcols, mpad * lcols});
+      ops.push_back(xop<T>(d->rank_of(r2, pc), true, Vt, mpad * lcols));
+      ops.push_back(xop<T>(d->rank_of(r2, pc), false, Vr + (size_t)k * mpad * lcols, mpad * lcols));
       ++k;
     }
     std::string terr;
@@ -798,7 +900,7 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
     rec(h, EV_FWD, sc);
     wait(h, s, EV_FWD);
     for (int i = 0; i < Pr - 1; ++i)
-      hipLaunchKernelGGL(add_inplace_kernel, dim3(1024), dim3(256), 0, s, Vt, Vr + (size_t)i * mpad * lcols,
+      hipLaunchKernelGGL(add_inplace_kernel<T>, dim3(1024), dim3(256), 0, s, Vt, Vr + (size_t)i * mpad * lcols,
                          (long)(mpad * lcols));
   }
   // |V_j|^2 over my tile columns; every rank of a process column holds the same sums
@@ -827,4 +929,8 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
   HIPCHK(h, e);
   HIPCHK(h, hipGetLastError());
   return GOGP_OK;
+}
+
+int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
+  return h->prec == 32 ? dist_produce_t<float>(h, Z, m, mu, sigma) : dist_produce_t<double>(h, Z, m, mu, sigma);
 }

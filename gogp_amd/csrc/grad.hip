@@ -185,16 +185,17 @@ int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
   return (int)(ntiles < GR_BLOCKS_MAX ? (ntiles > 0 ? ntiles : 1) : GR_BLOCKS_MAX);
 }
 
-void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
-                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out) {
+template <class KT>
+static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                                const double *X, const double *alpha, const KT *Kinv, int64_t ld,
+                                int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                                double *out) {
   const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, true, double>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                      Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L)
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
@@ -202,6 +203,18 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out, 0L);
+}
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out);
+}
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const float *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out);
 }
 
 // ---- gradient w.r.t. the inputs (full Observe form) ------------------------------

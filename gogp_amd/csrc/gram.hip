@@ -13,6 +13,8 @@
 // in LDS row-major (read as wave-uniform broadcasts), the column inputs
 // transposed [d][col] so that the 64 lanes of a wave read consecutive
 // addresses; each wave writes 512 contiguous bytes per output row.
+#include <algorithm>
+
 #include "kern_eval.h"
 
 namespace gogp {
@@ -81,9 +83,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
 
 // 2-D block-cyclic variant: rectangular grid over the LOCAL 64x64 tiles, global indices
 // through the block map (see common.h).
+template <class T>
 __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__restrict__ Pp,
                                                          const double *__restrict__ X, long n,
-                                                         double *__restrict__ Out, long ld, int ntc,
+                                                         T *__restrict__ Out, long ld, int ntc,
                                                          BlockMap map) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
   const int tx = tid & 63, ty = tid >> 6;
   if ((r0 >> map.nb_shift) < (c0 >> map.nb_shift)) {  // strictly upper distribution block: R := 0
 #pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) Out[(lr0 + ty * 16 + rr) * ld + lc0 + tx] = 0.0;
+    for (int rr = 0; rr < 16; ++rr) Out[(lr0 + ty * 16 + rr) * ld + lc0 + tx] = (T)0;
     return;
   }
   if (r0 + 63 < c0) return;  // upper tile inside a diagonal block: never read
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
     } else {
       k = (gi == gj) ? 1.0 : 0.0;
     }
-    Out[(lr0 + r) * ld + lc0 + tx] = k;
+    Out[(lr0 + r) * ld + lc0 + tx] = (T)k;
   }
 }
 
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
 __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restrict__ Pp,
                                                       const double *__restrict__ X, long n,
                                                       const double *__restrict__ v, long npad,
-                                                      int tiles_per_slab, double *__restrict__ part) {
+                                                      int tiles_per_slab, double *__restrict__ part,
+                                                      int tile_begin, int tile_end) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -154,8 +158,9 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restric
   // thread (tx, ty): row r0 + tx, columns ty*16 .. ty*16+15 of every tile
   double acc = 0.0;
   const long gi = r0 + tx;
-  const int ntile = (int)(npad / 64);
-  for (int t = slab * tiles_per_slab; t < (slab + 1) * tiles_per_slab && t < ntile; ++t) {
+  // column tiles [tile_begin, tile_end): all of them, or one rank's share of a sharded evaluation
+  for (int t = tile_begin + slab * tiles_per_slab; t < tile_begin + (slab + 1) * tiles_per_slab && t < tile_end;
+       ++t) {
     const long c0 = (long)t * 64;
     __syncthreads();
     for (int idx = tid; idx < 64 * D; idx += 256) {
@@ -185,14 +190,15 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restric
     part[(long)slab * npad + gi] = red[tx] + red[64 + tx] + red[128 + tx] + red[192 + tx];
 }
 
-// r_i = y_i - sum_slab part[slab][i]  (i < n; 0 beyond)
+// r_i = y_i - sum_slab part[slab][i]  (i < n; 0 beyond); without y: the plain sum (K v over a range
+// of columns, to be all-reduced)
 __global__ void kmatvec_finish_kernel(const double *__restrict__ part, int nslab, long npad, long n,
                                       const double *__restrict__ y, double *__restrict__ r) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
   double s = 0.0;
   for (int q = 0; q < nslab; ++q) s += part[(long)q * npad + i];
-  r[i] = (i < n) ? y[i] - s : 0.0;
+  r[i] = (i < n) ? (y ? y[i] - s : s) : 0.0;
 }
 
 void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -201,9 +207,25 @@ void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *
   const int tps = (ntile + nslab - 1) / nslab;
   const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
   hipLaunchKernelGGL(kmatvec_kernel, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n, v,
-                     (long)npad, tps, part);
+                     (long)npad, tps, part, 0, ntile);
   hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
                      (long)npad, (long)n, y, r);
+}
+
+// out_i = sum over the columns j of share `part_idx` of `nparts` of K_ij v_j (exact fp64 K): the
+// sharded form of the residual -- every rank takes its share of the column tiles, the shares are
+// all-reduced.
+void launch_kmatvec_share(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
+                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out) {
+  const int ntile = (int)(npad / 64);
+  const int per = (ntile + nparts - 1) / nparts;
+  const int t0 = std::min(ntile, part_idx * per), t1 = std::min(ntile, (part_idx + 1) * per);
+  const int tps = std::max(1, (t1 - t0 + nslab - 1) / nslab);
+  const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
+  hipLaunchKernelGGL(kmatvec_kernel, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n, v,
+                     (long)npad, tps, part, t0, t1);
+  hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
+                     (long)npad, (long)n, (const double *)nullptr, out);
 }
 
 __global__ void prior_kernel(const DevParams *__restrict__ Pp, const double *__restrict__ Z,
@@ -260,13 +282,22 @@ void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevP
   gram_lower_split_t(s_first, s_rest, p, ndim, X, n, npad, K, ld, wcols);
 }
 
-void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
-                       int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld) {
+template <class T>
+static void gram_local_t(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                         int64_t mrows, int64_t ncols, BlockMap map, T *K, int64_t ld) {
   const int ntr = (int)(mrows / 64), ntc = (int)(ncols / 64);
   if (ntr <= 0 || ntc <= 0) return;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL(gram_local_kernel, dim3(ntr * ntc), dim3(256), lds, s, p, X, (long)n, K, (long)ld,
+  hipLaunchKernelGGL(gram_local_kernel<T>, dim3(ntr * ntc), dim3(256), lds, s, p, X, (long)n, K, (long)ld,
                      ntc, map);
+}
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld) {
+  gram_local_t(s, p, ndim, X, n, mrows, ncols, map, K, ld);
+}
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, float *K, int64_t ld) {
+  gram_local_t(s, p, ndim, X, n, mrows, ncols, map, K, ld);
 }
 
 template <class T>

@@ -529,9 +529,10 @@ void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m
 // ---- helpers of the sharded (2-D block-cyclic) evaluation ------------------------------------
 
 // dst (n x n, ldd) = src (n x n, lds)^T, n a multiple of 32
-__global__ __launch_bounds__(256) void transpose_sq_kernel(const double *__restrict__ src, long lds_,
-                                                           double *__restrict__ dst, long ldd, int nt) {
-  __shared__ double tile[32][33];
+template <class T>
+__global__ __launch_bounds__(256) void transpose_sq_kernel(const T *__restrict__ src, long lds_,
+                                                           T *__restrict__ dst, long ldd, int nt) {
+  __shared__ T tile[32][33];
   const int bx = blockIdx.x % nt, by = blockIdx.x / nt;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -544,7 +545,12 @@ __global__ __launch_bounds__(256) void transpose_sq_kernel(const double *__restr
 void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
                          int n) {
   const int nt = n / 32;
-  hipLaunchKernelGGL(transpose_sq_kernel, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
+  hipLaunchKernelGGL(transpose_sq_kernel<double>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
+                     (long)ldd, nt);
+}
+void launch_transpose_sq(hipStream_t s, const float *src, int64_t lds_, float *dst, int64_t ldd, int n) {
+  const int nt = n / 32;
+  hipLaunchKernelGGL(transpose_sq_kernel<float>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
                      (long)ldd, nt);
 }
 
@@ -579,7 +585,8 @@ void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk,
 // Two stages, fixed summation order: workgroup (column group of 64, row slab of TDOT_SLAB rows)
 // writes part[slab][c]; the finish kernel adds the slabs.  part: (rows/TDOT_SLAB + 1) * nb doubles.
 constexpr int TDOT_SLAB = 256;
-__global__ __launch_bounds__(256) void chunk_tdot_kernel(const double *__restrict__ chunk, long rows,
+template <class T>
+__global__ __launch_bounds__(256) void chunk_tdot_kernel(const T *__restrict__ chunk, long rows,
                                                          int nb, const double *__restrict__ v,
                                                          double *__restrict__ part) {
   __shared__ double red[4][64];
@@ -590,10 +597,10 @@ __global__ __launch_bounds__(256) void chunk_tdot_kernel(const double *__restric
   double a0 = 0.0, a1 = 0.0;
   long r = r0 + wid;
   for (; r + 4 < r1; r += 8) {
-    a0 += chunk[r * nb + c] * v[r];
-    a1 += chunk[(r + 4) * nb + c] * v[r + 4];
+    a0 += (double)chunk[r * nb + c] * v[r];
+    a1 += (double)chunk[(r + 4) * nb + c] * v[r + 4];
   }
-  if (r < r1) a0 += chunk[r * nb + c] * v[r];
+  if (r < r1) a0 += (double)chunk[r * nb + c] * v[r];
   red[wid][lane] = a0 + a1;
   __syncthreads();
   if (wid == 0) part[(long)blockIdx.y * nb + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
@@ -609,17 +616,27 @@ __global__ void chunk_tdot_finish_kernel(const double *__restrict__ part, int ns
 
 int64_t chunk_tdot_scratch(int64_t max_rows, int nb) { return (max_rows / TDOT_SLAB + 1) * (int64_t)nb; }
 
+template <class T>
+static void chunk_tdot_t(hipStream_t s, const T *chunk, int64_t rows, int nb, const double *v, double *part,
+                         double *out) {
+  const int nslab = (int)((rows + TDOT_SLAB - 1) / TDOT_SLAB);
+  hipLaunchKernelGGL(chunk_tdot_kernel<T>, dim3(nb / 64, nslab), dim3(256), 0, s, chunk, (long)rows, nb, v, part);
+  hipLaunchKernelGGL(chunk_tdot_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, part, nslab, nb, out);
+}
 void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
                        double *part, double *out) {
-  const int nslab = (int)((rows + TDOT_SLAB - 1) / TDOT_SLAB);
-  hipLaunchKernelGGL(chunk_tdot_kernel, dim3(nb / 64, nslab), dim3(256), 0, s, chunk, (long)rows, nb, v, part);
-  hipLaunchKernelGGL(chunk_tdot_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, part, nslab, nb, out);
+  chunk_tdot_t(s, chunk, rows, nb, v, part, out);
+}
+void launch_chunk_tdot(hipStream_t s, const float *chunk, int64_t rows, int nb, const double *v,
+                       double *part, double *out) {
+  chunk_tdot_t(s, chunk, rows, nb, v, part, out);
 }
 
 // alpha partial of one rank: for every local row (local row block bi, global block
 // gI = bi*Pr + pr) out[global row] = sum over the local chunks bj with gP = bj*Pc + pc >= gI of
 // sum_c Ych[bj][bi][r][c] * z[gP*nb + c].  Ych: nloc chunks of (mloc*nb) x nb.  One wave per row.
-__global__ __launch_bounds__(256) void chunk_alpha_kernel(const double *__restrict__ Ych, int mloc,
+template <class T>
+__global__ __launch_bounds__(256) void chunk_alpha_kernel(const T *__restrict__ Ych, int mloc,
                                                           int nloc, int nb, BlockMap map,
                                                           const double *__restrict__ z,
                                                           double *__restrict__ out) {
@@ -633,13 +650,14 @@ __global__ __launch_bounds__(256) void chunk_alpha_kernel(const double *__restri
   for (int bj = 0; bj < nloc; ++bj) {
     const int gP = bj * map.Pc + map.pc;
     if (gP < gI) continue;
-    const double *row = Ych + bj * chunk_sz + lrow * nb;
+    const T *row = Ych + bj * chunk_sz + lrow * nb;
     const double *zz = z + (long)gP * nb;
     for (int c = lane * 2; c < nb; c += 128) {
-      const double2 y = *reinterpret_cast<const double2 *>(row + c);
+      double ya, yb;
+      load2(row + c, ya, yb);
       const double2 q = *reinterpret_cast<const double2 *>(zz + c);
-      s0 += y.x * q.x;
-      s1 += y.y * q.y;
+      s0 += ya * q.x;
+      s1 += yb * q.y;
     }
   }
   double sum = s0 + s1;
@@ -648,12 +666,21 @@ __global__ __launch_bounds__(256) void chunk_alpha_kernel(const double *__restri
   if (lane == 0) out[map.grow(lrow)] = sum;
 }
 
-void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
-                        const double *z, double *out) {
+template <class T>
+static void chunk_alpha_t(hipStream_t s, const T *Ych, int mloc, int nloc, int nb, BlockMap map, const double *z,
+                          double *out) {
   const long rows = (long)mloc * nb;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(chunk_alpha_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc,
+  hipLaunchKernelGGL(chunk_alpha_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc,
                      nloc, nb, map, z, out);
+}
+void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out) {
+  chunk_alpha_t(s, Ych, mloc, nloc, nb, map, z, out);
+}
+void launch_chunk_alpha(hipStream_t s, const float *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out) {
+  chunk_alpha_t(s, Ych, mloc, nloc, nb, map, z, out);
 }
 
 // acc[0] += sum_{i < nb, row0 + i < n} 2 log L[i][i]   (one diagonal block; single workgroup)

@@ -314,7 +314,8 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "precision"    64 | 32 fp64 throughout / the N x N matrices and the O(N^3) products in fp32
  *                          (v_mfma_f32_32x32x2_f32) with fp64 inputs, kernel evaluation, diagonal
  *                          blocks, vectors and reductions: BASELINE configs[4].  Set it before
- *                          gogp_set_data (it re-sizes the buffers); single-GPU only.    (default 64)
+ *                          gogp_set_data (it re-sizes the buffers) and before gogp_dist_init_*
+ *                          (a shard then holds float tiles and exchanges float panels)  (default 64)
  *   "refine_steps" 0..8    precision 32 only: steps of iterative refinement of alpha against
  *                          the exact (fp64, recomputed) Gram matrix                    (default 1)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable

@@ -128,6 +128,77 @@ def expected_exchange_bytes(npad, grid, nb=512):
     return total
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(1, 1), (1, 2), (2, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
+def test_sharded_fp32_tiles_keep_the_accuracy_contract(grid):
+    """precision = 32 on a sharded handle: float tiles, panels and exchanges, fp32 MFMA products;
+    fp64 diagonal tiles, log-determinant, z / alpha sums and one refinement step of alpha against
+    the exact Gram matrix (K alpha summed over the ranks' column shares).  The same contract as the
+    single-GPU fp32 path (DESIGN.md "fp32 path") against the fp64 oracle, and agreement with that
+    path to fp32 rounding; every rank returns the same numbers."""
+    from gogp_amd import configs, gp as G
+    from gogp_amd.sharded import ShardedGP
+    from oracle.oracle import FastOracle
+    import loopback
+    n = 2500
+    wl = configs.workload(5, n)
+    X, y = wl.inputs()
+    Z = wl.test_points(32)
+    x = wl.log_theta(0)
+    o = FastOracle(wl.D, wl.simil, wl.noise)
+    o.set_data(X, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    mu_o, sg_o = o.Produce(Z)
+    g1 = G.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, precision=32)
+    lml_1, grad_1 = g1.Observe(x), g1.Gradient()
+    g1.close()
+    world = grid[0] * grid[1]
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0, precision=32, grid=grid, rank=r,
+                       world=world, exchange=lb.exchange, allreduce=lb.allreduce)
+        out = []
+        for rep in range(2):
+            lml, grad = sh.Observe(x), sh.Gradient()
+            out.append((lml, grad))
+        mu, sg = sh.Produce(Z)
+        alpha = sh.Alpha
+        Lf = sh.L  # collective: the tiles are gathered on every rank
+        nbytes = sh.local_bytes()
+        sh.close()
+        return out, mu, sg, alpha, Lf, nbytes
+
+    outs, lb = loopback.run_ranks(world, rank_fn)
+    assert loopback.check_rendezvous(lb.log) is None
+    for (ev, mu, sg, alpha, Lf, nbytes) in outs:
+        (lml, grad), (lml2, grad2) = ev
+        # repeatable up to the summation order of the rehearsal transport's all-reduce
+        assert abs(lml - lml2) <= 1e-12 * abs(lml) and np.abs(grad - grad2).max() <= 1e-9 * np.abs(grad).max()
+        assert abs(lml - lml_o) <= 2e-6 * abs(lml_o), (lml, lml_o)
+        assert np.abs(grad - grad_o).max() <= 2e-5 * np.abs(grad_o).max()
+        assert np.abs(alpha - o.Alpha).max() <= 2e-5 * np.abs(o.Alpha).max()
+        assert np.abs(mu - mu_o).max() <= 1e-3 * np.abs(mu_o).max()
+        assert np.abs(sg - sg_o).max() <= 2e-4 * np.abs(sg_o).max()
+        assert abs(lml - lml_1) <= 2e-6 * abs(lml_1) and np.abs(grad - grad_1).max() <= 2e-5 * np.abs(grad_1).max()
+        assert lml == outs[0][0][0][0] and np.array_equal(grad, outs[0][0][0][1])  # same on every rank
+    Lf = outs[0][4]
+    th = np.exp(x)
+    kii = th[0] + th[-1] ** 2
+    for i in (0, 700, n - 1):
+        assert abs(float(Lf[i] @ Lf[i]) - kii) <= 1e-5 * kii
+    # float tiles: about half the bytes of the fp64 shard
+    if world >= 4:
+        def rank64(r, lb2):
+            sh = ShardedGP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                           exchange=lb2.exchange, allreduce=lb2.allreduce)
+            sh._push_data()  # the shard's buffers are sized when the data arrive
+            b = sh.local_bytes()
+            sh.close()
+            return b
+        b64, _ = loopback.run_ranks(world, rank64)
+        assert outs[0][5] < 0.62 * b64[0]
+
+
 def test_rendezvous_checker_finds_a_cyclic_wait():
     """The checker itself: two ranks that each send first and receive in their NEXT group pass on
     buffered queues and hang on RCCL; the same transfers in ONE group per rank are fine."""

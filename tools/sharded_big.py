@@ -12,6 +12,7 @@ from gogp_amd.sharded import ShardedGP
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 grid = tuple(int(v) for v in sys.argv[2].split("x")) if len(sys.argv) > 2 else (2, 4)
 nobs = int(sys.argv[3]) if len(sys.argv) > 3 else None
+prec = int(sys.argv[4]) if len(sys.argv) > 4 else 64  # 32: float tiles on the shards (reference below stays fp64)
 wl = configs.workload(cfg, nobs)
 X, y = wl.inputs()
 x = wl.log_theta(0)
@@ -24,7 +25,7 @@ ref.close()
 world = grid[0] * grid[1]
 
 def rank_fn(r, lb):
-    sh = ShardedGP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+    sh = ShardedGP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0, precision=prec, grid=grid, rank=r, world=world,
                    exchange=lb.exchange, allreduce=lb.allreduce)
     t0 = time.time()
     lml = sh.Observe(x)
@@ -40,9 +41,10 @@ for r, (lml, grad, mu, sg, al, nb, dt) in enumerate(outs):
     e = (abs(lml - lml_o) / abs(lml_o), np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
          np.abs(mu - mu_o).max() / np.abs(mu_o).max(), np.abs(sg - sg_o).max() / np.abs(sg_o).max(),
          np.abs(al - alpha_o).max() / np.abs(alpha_o).max())
-    assert e[0] < 1e-10 and e[1] < 1e-8 and e[2] < 1e-8 and e[3] < 1e-7 and e[4] < 1e-8, (r, e)
+    tol = (1e-10, 1e-8, 1e-8, 1e-7, 1e-8) if prec == 64 else (2e-6, 1e-4, 1e-3, 1e-3, 1e-4)  # fp32 contract
+    assert all(v < t for v, t in zip(e, tol)), (r, e)
     if r == 0:
-        print("config %d N=%d grid %dx%d: rel. errors vs single GPU: lml %.1e grad %.1e mu %.1e sigma %.1e alpha %.1e; "
+        print("config %d N=%d grid %dx%d, tiles fp%d: rel. errors vs single GPU (fp64): lml %.1e grad %.1e mu %.1e sigma %.1e alpha %.1e; "
               "%.2f GB per rank; %.2f GB exchanged per rank; %.1f s (host-synchronous rehearsal transport)" % (
-                  cfg, wl.N, grid[0], grid[1], *e, nb / 1e9, sum(lb.sent_bytes) / world / 1e9, dt), flush=True)
+                  cfg, wl.N, grid[0], grid[1], prec, *e, nb / 1e9, sum(lb.sent_bytes) / world / 1e9, dt), flush=True)
 print("ok")
