@@ -21,6 +21,7 @@ t_end = time.time() + seconds
 GRIDS = [(1, 1), (1, 2), (2, 2), (1, 3), (1, 4), (2, 4), (2, 6), (3, 3), (4, 4)]
 nrun = 0
 worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
+worst32 = dict(worst)
 while time.time() < t_end:
     name, D, simil, noise, ts, tn = CASES[rng.integers(0, len(CASES) - 1)]
     grid = GRIDS[rng.integers(0, len(GRIDS))]
@@ -32,14 +33,27 @@ while time.time() < t_end:
         y = (y - y.mean()) / y.std()
     x = np.log(np.array(list(ts) + list(tn)) * np.exp(0.1 * rng.normal(size=len(ts) + len(tn))))
     Z = rng.uniform(-0.1, 1.1, (int(rng.integers(1, 200)), D))
+    prec = 32 if rng.integers(0, 4) == 0 else 64  # one run in four with float tiles
     ref = G.GP(D, simil, noise, X=X, Y=y, device=0)
     lml_o, grad_o = ref.Observe(x), ref.Gradient()
     mu_o, sigma_o = ref.Produce(Z)
     ref.close()
+    e32 = None
+    if prec == 32:
+        # what float matrices cost on ONE GPU for this very matrix: the bound for the float shards
+        # (the error depends on cond(K), which the random parameters move by orders of magnitude)
+        r32 = G.GP(D, simil, noise, X=X, Y=y, device=0, precision=32)
+        l32, g32 = r32.Observe(x), r32.Gradient()
+        m32, s32 = r32.Produce(Z)
+        r32.close()
+        e32 = {"lml": abs(l32 - lml_o) / max(1.0, abs(lml_o)),
+               "grad": np.abs(g32 - grad_o).max() / max(1.0, np.abs(grad_o).max()),
+               "mu": np.abs(m32 - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
+               "sigma": np.nanmax(np.abs(s32 - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
     order = int(rng.integers(0, 3))
 
     def rank_fn(r, lb):
-        sh = ShardedGP(D, simil, noise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+        sh = ShardedGP(D, simil, noise, X=X, Y=y, device=0, precision=prec, grid=grid, rank=r, world=world,
                        exchange=lb.exchange, allreduce=lb.allreduce)
         lml = sh.Observe(x)
         if order == 1:
@@ -48,7 +62,8 @@ while time.time() < t_end:
         if order == 2:
             sh.ThetaSimil, sh.ThetaNoise = list(np.exp(x[:len(ts)])), list(np.exp(x[len(ts):]))
             sh.Absorb(X, y)
-            assert abs(sh.LML() - lml) <= 1e-12 * max(1.0, abs(lml))
+            # (float tiles: exp(log(theta)) is one ulp off and flips last bits of rounded-to-fp32 entries)
+            assert abs(sh.LML() - lml) <= (1e-12 if prec == 64 else 1e-7) * max(1.0, abs(lml))
         mu, sigma = sh.Produce(Z)
         sh.close()
         return lml, grad, mu, sigma
@@ -59,14 +74,24 @@ while time.time() < t_end:
              "grad": np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
              "mu": np.abs(mu - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
              "sigma": np.nanmax(np.abs(sigma - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
+        w = worst if prec == 64 else worst32
         for k in e:
-            worst[k] = max(worst[k], float(e[k]))
-        if e["lml"] > 1e-9 or e["grad"] > 1e-7 or e["mu"] > 1e-6 or e["sigma"] > 1e-5:
-            print("MISMATCH", name, n, grid, order, e, flush=True)
+            w[k] = max(w[k], float(e[k]))
+        if prec == 64:
+            tol = (1e-9, 1e-7, 1e-6, 1e-5)
+        else:  # no worse than 3x the single-GPU fp32 path on the same matrix (+ a rounding floor)
+            # for LML and gradient; Produce differs between the paths (V = Y^T Kstar with the explicit fp32
+            # inverse here, a blocked solve with L there) and sigma^2 = prior - |V|^2 cancels heavily for dense
+            # 1-D inputs: measured up to 5e-3 here against 2e-4 there -- fixed loose bounds for mu, sigma
+            # (the log-determinant's fp32 rounding path differs as well: measured 0.4x .. 5x the single-GPU
+            # error on the same matrix, identical on every grid)
+            tol = (10.0 * e32["lml"] + 1e-4, 3.0 * e32["grad"] + 1e-4, 3e-2, 3e-2)
+        if e["lml"] > tol[0] or e["grad"] > tol[1] or e["mu"] > tol[2] or e["sigma"] > tol[3]:
+            print("MISMATCH", name, n, grid, order, "precision", prec, e, "single-GPU fp32:", e32, flush=True)
             sys.exit(1)
     nrun += 1
     if nrun % 10 == 0:
         print("  ... %d sharded evaluations OK (last: %s n=%d grid=%s), %.0f s left" % (
             nrun, name, n, grid, t_end - time.time()), flush=True)
-print("sharded stress: %d evaluations OK in %.0f s; worst relative errors vs the single-GPU path %s" % (
-    nrun, seconds, worst), flush=True)
+print("sharded stress: %d evaluations OK in %.0f s; worst relative errors vs the single-GPU fp64 path %s; float tiles %s" % (
+    nrun, seconds, worst, worst32), flush=True)
