@@ -1416,11 +1416,11 @@ extern "C" int gogp_get_factor_rows(gogp_handle *h, const int64_t *rows, int64_t
   if (!h || nrows < 0 || (nrows > 0 && (!rows || !out))) return GOGP_EARG;
   if (nrows == 0 || h->n == 0) return GOGP_OK;
   if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
-  if (h->dist) return fail(h, GOGP_ESTATE, "L rows: not available on a sharded handle");
   HIPCHK(h, hipSetDevice(h->device));
   const int64_t n = h->n;
   for (int64_t r = 0; r < nrows; ++r)
     if (rows[r] < 0 || rows[r] >= n) return fail(h, GOGP_EARG, "get_factor_rows: row out of range");
+  if (h->dist) return gogp_dist_get_factor_part(h, rows, nrows, out);  // collective: the tiles' owners contribute
   std::vector<float> tmp32(h->prec == 32 ? (size_t)n : 0);
   for (int64_t r = 0; r < nrows; ++r) {
     const int64_t i = rows[r];
@@ -1443,8 +1443,8 @@ extern "C" int gogp_get_factor_diag(gogp_handle *h, double *diag) {
   if (!h || (h->n > 0 && !diag)) return GOGP_EARG;
   if (h->n == 0) return GOGP_OK;
   if (!h->factored) return fail(h, GOGP_ESTATE, "L: nothing absorbed");
-  if (h->dist) return fail(h, GOGP_ESTATE, "L diagonal: not available on a sharded handle");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->dist) return gogp_dist_get_factor_part(h, nullptr, 0, diag);  // collective
   if (h->prec == 32) {
     std::vector<float> d32((size_t)h->n);
     HIPCHK(h, hipMemcpy2D(d32.data(), sizeof(float), h->bufL, (size_t)(h->npad + 1) * sizeof(float),

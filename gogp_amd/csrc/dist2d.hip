@@ -766,6 +766,76 @@ int gogp_dist_get_factor(gogp_handle *h, double *Lout) {
   return h->prec == 32 ? dist_get_factor_t<float>(h, Lout) : dist_get_factor_t<double>(h, Lout);
 }
 
+// Selected rows of L (mode 0: out is nrows x n) or its diagonal (mode 1: rows = nullptr, out has n
+// entries): every rank writes what its tiles hold into a zeroed device buffer, one all-reduce
+// completes it on every rank (collective).
+template <class T>
+__global__ void gather_rows_of_l_kernel(const T *__restrict__ Lch, int mloc, int nloc, int nb, BlockMap map,
+                                        const long *__restrict__ rows, long nrows, long n, int diag_only,
+                                        double *__restrict__ out) {
+  const long k = blockIdx.x;                       // requested row (or, diag_only, the row itself)
+  const long r = diag_only ? k : rows[k];
+  const int gI = (int)(r / nb);
+  if (gI % map.Pr != map.pr) return;               // not one of my tile rows
+  const int bi = gI / map.Pr;
+  const long lr = r - (long)gI * nb;
+  const long chunk_sz = (long)mloc * nb * nb;
+  for (int bj = 0; bj < nloc; ++bj) {
+    const int gP = bj * map.Pc + map.pc;
+    if (gP > gI) break;
+    const T *src = Lch + bj * chunk_sz + ((long)bi * nb + lr) * nb;
+    if (diag_only) {
+      if (gP == gI && threadIdx.x == 0) out[r] = (double)src[lr];
+      continue;
+    }
+    for (int c = threadIdx.x; c < nb; c += blockDim.x) {
+      const long gc = (long)gP * nb + c;
+      if (gc < n && gc <= r) out[k * n + gc] = (double)src[c];
+    }
+  }
+}
+
+template <class T>
+static int dist_get_factor_part_t(gogp_handle *h, const int64_t *rows, int64_t nrows, double *out) {
+  Dist2D *d = h->dist;
+  const int64_t n = h->n;
+  const bool diag_only = rows == nullptr;
+  const int64_t count = diag_only ? n : nrows * n, nblocks = diag_only ? n : nrows;
+  for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, d->sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  double *tmp = nullptr;
+  long *drows = nullptr;
+  HIPCHK(h, hipMalloc(&tmp, (size_t)count * sizeof(double)));
+  hipError_t e = hipMemsetAsync(tmp, 0, (size_t)count * sizeof(double), d->sc);
+  if (e == hipSuccess && !diag_only) {
+    e = hipMalloc(&drows, (size_t)nrows * sizeof(long));
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(drows, rows, (size_t)nrows * sizeof(long), hipMemcpyHostToDevice, d->sc);
+  }
+  if (e == hipSuccess)
+    hipLaunchKernelGGL(gather_rows_of_l_kernel<T>, dim3((unsigned)nblocks), dim3(256), 0, d->sc,
+                       d->mat<T>(d->Lch), d->mloc, d->nloc, d->nb, d->map(), drows, (long)nrows, (long)n,
+                       diag_only ? 1 : 0, tmp);
+  int rc = GOGP_OK;
+  std::string terr;
+  if (e == hipSuccess) rc = d->tr->allreduce(d->sc, tmp, count, &terr);
+  if (e == hipSuccess && rc == GOGP_OK)
+    e = hipMemcpyAsync(out, tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, d->sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->sc);
+  (void)hipFree(tmp);
+  (void)hipFree(drows);
+  if (rc != GOGP_OK) {
+    h->err = "sharded get_factor_rows: " + terr;
+    return rc;
+  }
+  HIPCHK(h, e);
+  return GOGP_OK;
+}
+int gogp_dist_get_factor_part(gogp_handle *h, const int64_t *rows, int64_t nrows, double *out) {
+  static_assert(sizeof(long) == sizeof(int64_t), "row indices are copied as they are");
+  return h->prec == 32 ? dist_get_factor_part_t<float>(h, rows, nrows, out)
+                       : dist_get_factor_part_t<double>(h, rows, nrows, out);
+}
+
 // ---- Produce on a sharded handle -----------------------------------------------------------------
 // gp.GP.Produce (gp/gp.go:258-360) with L never leaving its ranks:  sigma_j^2 = k(z_j, z_j) -
 // |L^-1 k*_j|^2 and L^-1 = Y^T, so with V = Y^T Kstar:  V[P-block, j] = sum_{I <= P} Y[I, P]^T

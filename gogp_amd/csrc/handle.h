@@ -171,3 +171,5 @@ int gogp_dist_factorize(gogp_handle *h, bool want_kinv);
 int gogp_dist_gradient_sums(gogp_handle *h, double *hacc /* NACC, pinned host */);
 int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma);
 int gogp_dist_get_factor(gogp_handle *h, double *Lout /* n*n, every rank */);
+// rows != nullptr: nrows selected rows of L (nrows x n); rows == nullptr: the diagonal (n); collective
+int gogp_dist_get_factor_part(gogp_handle *h, const int64_t *rows, int64_t nrows, double *out);

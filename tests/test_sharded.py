@@ -86,6 +86,9 @@ def test_sharded_grid_matches_single_gpu(grid):
                 Lf = sh.L
                 assert np.abs(Lf @ Lf.T - ref["K"]).max() <= 1e-10 * np.abs(ref["K"]).max()
                 assert np.allclose(np.triu(Lf, 1), 0.0)
+                rows = np.array([0, n // 3, 513 % n, n - 1])  # selected rows and the diagonal: collective too
+                np.testing.assert_array_equal(sh.L_rows(rows), Lf[rows])
+                np.testing.assert_array_equal(sh.L_diag(), np.diag(Lf))
             nbytes = sh.local_bytes()
             sh.close()
             return nbytes
