@@ -439,6 +439,25 @@ def main():
                         "one-launch-sequence form"}
             for gg in gps[1:]:
                 gg.close()
+        if world == 1 and not args.no_produce and g is not None:
+            # configs[4] words the workload as "LML+grad inside L-BFGS hyperparameter loop": a few major
+            # iterations of the optimiser on this handle (gogp_amd/optimize.py) -- the same
+            # evaluations, now chosen by the line search
+            from gogp_amd import optimize
+            iters = 2 if N > 40000 else 4
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            try:
+                res = optimize.lbfgs(g, wl.log_theta(0), major_iterations=iters, gradient_threshold=1e-9)
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - tl
+                out["lbfgs_loop"] = {
+                    "major_iterations": res.iterations, "evaluations": res.evaluations, "seconds": tl,
+                    "evals_per_s": res.evaluations / tl, "lml_start": res.history[0], "lml_end": res.lml,
+                    "note": "optimize.lbfgs from the first theta: every trial point is one Observe (+ Gradient "
+                            "when accepted) on the resident data"}
+            except Exception as e:  # noqa: BLE001
+                out["lbfgs_loop"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_produce and g is not None and N <= 40000:
             # the boundary's host-buffer form (gogp_set_data: X, y from host memory): the same
             # evaluation with the inputs re-sent over PCIe every step -- never `value`
