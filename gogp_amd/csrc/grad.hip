@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void xgrad_kernel(const DevParams *__restrict_
                                                     const double *__restrict__ X,
                                                     const double *__restrict__ alpha,
                                                     const double *__restrict__ Kinv, long ld,
-                                                    long n, long npad, double *__restrict__ gx) {
+                                                    long n, long npad, double *__restrict__ gx, int d0) {
   extern __shared__ double sm[];
   const DevParams &P = *Pp;
   const int D = P.ndim;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void xgrad_kernel(const DevParams *__restrict_
           const double W = ai * aj[j] - T[r * 65 + j];
           const double *xj = Xj + j * D;
           simil_xgrad_accum<DMAX>(
-              P, [&](int d) { return xi[d]; }, [&](int d) { return xj[d]; }, W, acc);
+              P, [&](int d) { return xi[d]; }, [&](int d) { return xj[d]; }, W, acc, d0);
         }
       }
     }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void xgrad_kernel(const DevParams *__restrict_
     double v = acc[d];
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
-    if (q == 0 && d < D && r0 + r < n) gx[(r0 + r) * D + d] = v;
+    if (q == 0 && d0 + d < D && r0 + r < n) gx[(r0 + r) * D + d0 + d] = v;
   }
 }
 
@@ -310,19 +310,22 @@ void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
   const size_t lds = (size_t)(128 * ndim + 64 * 65 + 64) * sizeof(double);
   const dim3 grid((unsigned)(npad / 64));
   // above 64 KB of dynamic LDS (D > 32) the limit has to be raised explicitly
-#define GOGP_LAUNCH_XG(DM)                                                                     \
+#define GOGP_LAUNCH_XG(DM, D0)                                                                 \
   do {                                                                                         \
     if (lds > 64 * 1024)                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xgrad_kernel<DM>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
     hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
-                       (long)n, (long)npad, gx);                                               \
+                       (long)n, (long)npad, gx, D0);                                           \
   } while (0)
-  if (ndim <= 4) GOGP_LAUNCH_XG(4);
-  else if (ndim <= 8) GOGP_LAUNCH_XG(8);
-  else if (ndim <= 16) GOGP_LAUNCH_XG(16);
-  else if (ndim <= 32) GOGP_LAUNCH_XG(32);
-  else GOGP_LAUNCH_XG(64);
+  // more than 32 dimensions: passes of 32 (a 64-accumulator instance needs 326 VGPRs, AGPRs included,
+  // and 128 SGPR spills -- the register footprint that produced wrong sums in the parameter-gradient
+  // reduction; see launch_grad_reduce)
+  if (ndim <= 4) GOGP_LAUNCH_XG(4, 0);
+  else if (ndim <= 8) GOGP_LAUNCH_XG(8, 0);
+  else if (ndim <= 16) GOGP_LAUNCH_XG(16, 0);
+  else
+    for (int d0 = 0; d0 < ndim; d0 += 32) GOGP_LAUNCH_XG(32, d0);
 #undef GOGP_LAUNCH_XG
 }
 

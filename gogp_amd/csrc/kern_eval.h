@@ -137,12 +137,12 @@ __device__ __forceinline__ void simil_grad_accum(const DevParams &P, FA xa, FB x
   }
 }
 
-// Accumulate  W * dk(xa, xb)/dxa_d  into acc[d]  (d < ndim <= DMAX): the
+// Accumulate  W * dk(xa, xb)/dxa_d  into acc[d - d0]  (d0 <= d < min(ndim, d0 + DMAX)): the
 // derivative the AD tape yields for the first input (gp/gp.go:118-123).  For the
 // stationary kernels here dk/dxb = -dk/dxa.
 template <int DMAX, class FA, class FB>
 __device__ __forceinline__ void simil_xgrad_accum(const DevParams &P, FA xa, FB xb, double W,
-                                                  double *acc) {
+                                                  double *acc, int d0 = 0) {
   const int D = P.ndim;
   for (int t = 0; t < P.nterms; ++t) {
     const int kind = P.kind[t];
@@ -156,7 +156,8 @@ __device__ __forceinline__ void simil_xgrad_accum(const DevParams &P, FA xa, FB 
       }
       const double cf = W * c * exp(-2.0 * s) * (-4.0) * w;
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d)
+      for (int q = 0; q < DMAX; ++q) {
+        const int d = d0 + q;
         if (d < D) {
           const double dx = xa(d) - xb(d);
           const double phi = w * fabs(dx);
@@ -164,8 +165,9 @@ __device__ __forceinline__ void simil_xgrad_accum(const DevParams &P, FA xa, FB 
           sincos(phi, &sn, &cs);
           const double il = P.inv_len[t][d];
           const double sg = dx > 0.0 ? 1.0 : (dx < 0.0 ? -1.0 : 0.0);
-          acc[d] += cf * (sn * il) * cs * il * sg;
+          acc[q] += cf * (sn * il) * cs * il * sg;
         }
+      }
     } else {
       double s = 0.0;
       for (int d = 0; d < D; ++d) {
@@ -176,11 +178,13 @@ __device__ __forceinline__ void simil_xgrad_accum(const DevParams &P, FA xa, FB 
       radial_eval(kind, s, f, dfdr2);
       const double g = W * c * dfdr2 * 2.0;
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d)
+      for (int q = 0; q < DMAX; ++q) {
+        const int d = d0 + q;
         if (d < D) {
           const double il = P.inv_len[t][d];
-          acc[d] += g * (xa(d) - xb(d)) * il * il;
+          acc[q] += g * (xa(d) - xb(d)) * il * il;
         }
+      }
     }
   }
 }
