@@ -10,6 +10,9 @@ wl = configs.workload(cfg, nobs)
 X, y = wl.inputs()
 g = G.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0)
 import os
+if os.environ.get("CAND_SUPERPANEL"):
+    g.set_option("superpanel", int(os.environ["CAND_SUPERPANEL"]))
+    print("superpanel", os.environ["CAND_SUPERPANEL"], flush=True)
 if os.environ.get("CAND_GRAPH"):
     g.set_option("graph", 1)
     print("hipGraph replay on", flush=True)
