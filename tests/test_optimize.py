@@ -164,3 +164,41 @@ def test_lbfgs_batched_line_search_on_gpu_is_bit_identical():
     assert abs(q4.lml - q1.lml) <= 1e-12 * abs(q1.lml)
     g1.close()
     g4.close()
+
+
+def test_lbfgs_multistart_runs_take_the_paths_of_single_runs():
+    """k restarts in lock-step (one batched evaluation per round) = k separate lbfgs runs."""
+    rng = np.random.default_rng(2)
+    M = rng.normal(size=(4, 4))
+    A = M @ M.T + 0.5 * np.eye(4)
+    b = rng.normal(size=4) * 3
+    starts = rng.normal(size=(3, 4))
+    singles = [optimize.lbfgs(Quadratic(A, b), x0, gradient_threshold=1e-7) for x0 in starts]
+    m = _BatchedQuadratic(A, b)
+    multi = optimize.lbfgs_multistart(m, starts, gradient_threshold=1e-7)
+    for a, c in zip(multi, singles):
+        assert a.converged and a.iterations == c.iterations and a.evaluations == c.evaluations
+        np.testing.assert_allclose(a.x, c.x, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(a.history, c.history, rtol=1e-13)
+    assert m.batches <= max(c.evaluations for c in singles)  # rounds, not evaluations
+
+
+@pytest.mark.gpu
+def test_lbfgs_multistart_on_gpu():
+    """Three restarts on the HIP path: each run is bit for bit the single run from its start, the GP
+    ends at the best optimum."""
+    from gogp_amd import gp as G
+    from gogp_amd import synth
+    n, D = 500, 2
+    X, y = synth.make_inputs(n, D, 79)
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    starts = np.log([[2.0, 0.2, 0.7], [0.5, 1.0, 0.3], [1.0, 0.5, 0.5]])
+    g = G.GP(D, simil, noise, X=X, Y=y)
+    singles = [optimize.lbfgs(g, x0, gradient_threshold=1e-5, major_iterations=40) for x0 in starts]
+    multi = optimize.lbfgs_multistart(g, starts, gradient_threshold=1e-5, major_iterations=40)
+    for a, c in zip(multi, singles):
+        np.testing.assert_array_equal(a.x, c.x)
+        assert a.lml == c.lml and a.iterations == c.iterations
+    best = max(multi, key=lambda r: r.lml)
+    assert g.LML() == best.lml
+    g.close()
