@@ -103,7 +103,13 @@ def Evaluate(gp, m, theta, rdr, wtr, log=sys.stderr) -> None:
         if len(gp.X) > MINOPT:
             if ALG == "lbfgs":
                 try:
-                    result = optimize.lbfgs(m, x, major_iterations=ITERS, gradient_threshold=THRESHOLD)
+                    # optimize.Settings.Concurrent = NTASKS (tutorial.go:141): evaluate that many trial
+                    # points per round -- here the line search's next NTASKS steps in one launch
+                    # sequence (hyperparameters-only form on a GP / gp.Model with the candidates call)
+                    conc = NTASKS if (NTASKS > 1 and not OPTINP and
+                                      hasattr(getattr(m, "GP", m), "observe_gradient_candidates")) else 1
+                    result = optimize.lbfgs(m, x, major_iterations=ITERS, gradient_threshold=THRESHOLD,
+                                            line_search_candidates=conc)
                     if not result.converged and result.iterations <= MINITERS:
                         print("%d: stuck after %d iterations" % (end, result.iterations), file=log)
                     x = result.x

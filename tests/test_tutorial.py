@@ -50,14 +50,14 @@ class OracleGP:
 @pytest.fixture()
 def knobs():
     saved = {k: getattr(tutorial, k) for k in
-             ("OPTINP", "MINOPT", "ALG", "ITERS", "THRESHOLD", "RATE", "NONORMALIZE", "OUTOFSAMPLE", "SEED")}
+             ("OPTINP", "MINOPT", "ALG", "ITERS", "THRESHOLD", "RATE", "NONORMALIZE", "OUTOFSAMPLE", "SEED", "NTASKS")}
     yield tutorial
     for k, v in saved.items():
         setattr(tutorial, k, v)
 
 
 DEFAULTS = dict(OPTINP=False, MINOPT=0, ALG="lbfgs", ITERS=1000, THRESHOLD=1e-6, RATE=0.01,
-                NONORMALIZE=False, OUTOFSAMPLE=False, SEED=None)
+                NONORMALIZE=False, OUTOFSAMPLE=False, SEED=None, NTASKS=0)
 
 
 def _run(gp, golden_dir, model=None, data="barebones.csv", ntheta=3, **kn):
@@ -131,6 +131,11 @@ def test_evaluate_hip_matches_oracle(knobs, golden_dir):
     for g, w in zip(got, want):
         assert abs(g[5] - w[5]) <= 1e-3 * max(1.0, abs(w[5])), (g, w)   # final LML
         assert abs(g[2] - w[2]) <= 1e-3 * max(1.0, abs(w[2])), (g, w)   # forecast mean
+    # NTASKS = 4 (optimize.Settings.Concurrent, tutorial.go:141): four trial steps per launch sequence,
+    # the identical optimisation path -> the identical output text
+    seq, seq_text = _run(G.GP(1, SIMIL, NOISE), golden_dir, SEED=12, ITERS=30)
+    par, par_text = _run(G.GP(1, SIMIL, NOISE), golden_dir, SEED=12, ITERS=30, NTASKS=4)
+    assert par_text == seq_text
     # full form (inputs and outputs in x), a few steps
     want, _ = _run(OracleGP(1, SIMIL, NOISE), golden_dir, SEED=13, OPTINP=True, ITERS=2)
     got, _ = _run(G.GP(1, SIMIL, NOISE), golden_dir, SEED=13, OPTINP=True, ITERS=2)
