@@ -257,6 +257,7 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   h->P = h->ns + h->nn;
   for (int t = 0; t < desc->nterms; ++t)
     if (desc->terms[t].ard) h->ard_dims = desc->ndim;
+  h->radial1 = desc->nterms == 1 && desc->terms[0].kind != GOGP_K_PERIODIC;
   h->theta_s.assign(h->ns, 0.0);  // gp/gp.go:50-56
   h->theta_n.assign(h->nn > 0 ? h->nn : 1, 0.0);
   hipError_t e = hipSetDevice(device);
@@ -933,10 +934,10 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
       AuxTimer tm(h, GOGP_PROF_GRAD, s);
       if (h->prec == 32)
         launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha,
-                           reinterpret_cast<const float *>(h->bufA), h->npad, h->n, h->npad, h->gpart, h->gout);
+                           reinterpret_cast<const float *>(h->bufA), h->npad, h->n, h->npad, h->gpart, h->gout, h->radial1);
       else
         launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
-                           h->npad, h->gpart, h->gout);
+                           h->npad, h->gpart, h->gout, h->radial1);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1147,7 +1148,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     {
       AuxTimer tm(h, GOGP_PROF_GRAD, h->s);
       launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n, h->npad,
-                         h->gpart, h->gout);
+                         h->gpart, h->gout, h->radial1);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
     // every stream joins the main one (the end of a captured graph; harmless otherwise)

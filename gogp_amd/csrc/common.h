@@ -135,7 +135,7 @@ void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float 
                           int cols);
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims, const double *X,
                         const double *alpha, const float *Kinv, int64_t ld, int64_t n, int64_t npad,
-                        double *partials, double *out);
+                        double *partials, double *out, bool radial1 = false);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
@@ -193,18 +193,18 @@ int grad_reduce_blocks(int64_t npad);
 // fused gradient reduction over lower tiles of Kinv; out: NACC doubles
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
-                        int64_t npad, double *partials, double *out);
+                        int64_t npad, double *partials, double *out, bool radial1 = false);
 // the same over the LOCAL tiles (mrows x ncols, leading dimension ld) of a 2-D block-cyclic
 // K^-1: tiles of the global lower triangle only; `partials` needs grad_reduce_blocks_local
 int grad_reduce_blocks_local(int64_t mrows, int64_t ncols);
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out);
+                              double *out, bool radial1 = false);
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const float *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out);
+                              double *out, bool radial1 = false);
 
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}

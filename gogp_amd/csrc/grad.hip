@@ -20,7 +20,9 @@ constexpr int GR_BLOCKS_MAX = 2048;
 // LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
 // grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
 // KT: element type of K^-1 (float on the fp32 path; all sums are fp64 either way).
-template <int ARD_D, bool LOCAL, class KT>
+// RADIAL1: the similarity kernel is ONE radial term (every BASELINE configuration; the host checks):
+// that instance carries only the restructured loops below, the other only the generic accumulation.
+template <int ARD_D, bool LOCAL, class KT, bool RADIAL1>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X,
     const double *__restrict__ alpha, const KT *__restrict__ Kinv, long ld, long n, int nt,
@@ -77,7 +79,70 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
     const long gj = c0 + tx;
     const double *cj = CjT + tx;
     const double ajv = aj[tx];
-    for (int rr = 0; rr < 16; ++rr) {
+    if (RADIAL1) {
+      // One radial term: dimension loops outside, the thread's 16 rows
+      // inside (gram.hip has the same structure).  The column coordinate is read from LDS once per
+      // dimension, the rows' coordinates are wave-uniform and come from X through scalar loads (X is
+      // padded to npad rows).  Per accumulator the same additions in the same order as
+      // simil_grad_accum(): bit-identical sums.
+      const int rbase = __builtin_amdgcn_readfirstlane(ty) * 16;
+      const double *xr = X + (r0 + rbase) * D;
+      double s[16];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) s[rr] = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double il = P.inv_len[0][d];
+        const double c = cj[d * 64];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const double u = (xr[rr * D + d] - c) * il;
+          s[rr] += u * u;
+        }
+      }
+      const int kind = P.kind[0];
+      const double cc = P.c[0];
+      const bool isard = P.ard[0] != 0;
+      double gg[16];
+      unsigned live = 0;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int r = rbase + rr;
+        const long gi = r0 + r;
+        gg[rr] = 0.0;
+        if (gi < n && gj <= gi) {
+          const double w = ai[r] * ajv - (double)Kinv[(lr0 + r) * ld + lc0 + tx];
+          const double wgt = (gj < gi) ? 2.0 * w : w;
+          double f, dfdr2;
+          radial_eval(kind, s[rr], f, dfdr2);
+          acc[0] += wgt * cc * f;
+          const double g = wgt * cc * dfdr2 * (-2.0);
+          if (!isard) acc[1] += g * s[rr];
+          if (gi == gj) acc[ACC_TRACE] += w;
+          gg[rr] = g;
+          live |= 1u << rr;
+        }
+      }
+      if (ARD_D > 0 && isard) {
+#pragma unroll 1
+        for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {
+          const int d = ard0 + q;
+          if (d >= D) break;
+          const double il = P.inv_len[0][d];
+          const double c = cj[d * 64];
+          double a = ard[q];
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr)
+            if (live & (1u << rr)) {
+              const double g = gg[rr];
+              const double u = (xr[rr * D + d] - c) * il;
+              a += g * u * u;
+            }
+          ard[q] = a;
+        }
+      }
+      continue;
+    }
+    for (int rr = 0; RADIAL1 ? false : rr < 16; ++rr) {
       const int r = ty * 16 + rr;
       const long gi = r0 + r;
       if (gi < n && gj <= gi) {
@@ -149,7 +214,7 @@ int grad_reduce_blocks(int64_t npad) {
 template <class KT>
 static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                           const double *X, const double *alpha, const KT *Kinv, int64_t ld,
-                          int64_t n, int64_t npad, double *partials, double *out) {
+                          int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
@@ -160,8 +225,16 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
 // SGPR spill lanes copied through AGPRs -- returned wrong, run-to-run varying sums on the sharded
 // path at N >= 4096: tools/grad_probe.py.)
 #define GOGP_LAUNCH_GR(AD, A0)                                                                    \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0, tl_batch.stride)
+  do {                                                                                            \
+    if (radial1)                                                                                  \
+      hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
+                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
+                         tl_batch.stride);                                                        \
+    else                                                                                          \
+      hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT, false>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
+                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
+                         tl_batch.stride);                                                        \
+  } while (0)
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
   else
@@ -171,13 +244,13 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out) {
-  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
+                        int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1);
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const float *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out) {
-  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
+                        int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1);
 }
 
 int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
@@ -189,14 +262,20 @@ template <class KT>
 static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                                 const double *X, const double *alpha, const KT *Kinv, int64_t ld,
                                 int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                                double *out) {
+                                double *out, bool radial1) {
   const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
   const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
-  hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L)
+  do {                                                                                            \
+    if (radial1)                                                                                  \
+      hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
+    else                                                                                          \
+      hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
+  } while (0)
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
   else
@@ -207,14 +286,14 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out) {
-  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out);
+                              double *out, bool radial1) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1);
 }
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const float *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out) {
-  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out);
+                              double *out, bool radial1) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1);
 }
 
 // ---- gradient w.r.t. the inputs (full Observe form) ------------------------------

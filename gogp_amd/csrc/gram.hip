@@ -64,6 +64,44 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
   const int tx = tid & 63, ty = tid >> 6;
   const long gj = c0 + tx;
   const double *cj = CjT + tx;
+  if (!CROSS && P.nterms == 1 && P.kind[0] != GOGP_K_PERIODIC) {
+    // One radial term (every BASELINE configuration): dimension loop outside, the thread's 16 rows
+    // inside.  The column coordinate is read from LDS once per dimension instead of once per
+    // (row, dimension), and the rows' coordinates are wave-uniform: they come straight from X
+    // through scalar loads (X is padded to npad rows), not through LDS.  Same operations in the same
+    // order per pair as simil_value() -- bit-identical -- at 1/32 of its LDS reads.
+    const int rbase = __builtin_amdgcn_readfirstlane(ty) * 16;
+    const double *xr = Rsrc + (r0 + rbase) * D;
+    double s[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) s[rr] = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double il = P.inv_len[0][d];
+      const double c = cj[d * 64];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const double u = (xr[rr * D + d] - c) * il;
+        s[rr] += u * u;
+      }
+    }
+    const int kind = P.kind[0];
+    const double c0s = P.c[0];
+#pragma unroll 2
+    for (int rr = 0; rr < 16; ++rr) {
+      const long gi = r0 + rbase + rr;
+      double k;
+      if (gi < nrows && gj < ncols) {
+        double f, dfdr2;
+        radial_eval(kind, s[rr], f, dfdr2);
+        k = 0.0 + c0s * f;
+        if (gi == gj) k += P.noise_var;
+      } else {
+        k = (gi == gj) ? 1.0 : 0.0;
+      }
+      Out[gi * ld + gj] = (T)k;
+    }
+    return;
+  }
 #pragma unroll 2
   for (int rr = 0; rr < 16; ++rr) {
     const int r = ty * 16 + rr;

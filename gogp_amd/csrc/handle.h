@@ -20,6 +20,7 @@ struct gogp_handle {
   int device = 0;
   int ns = 0, nn = 0, P = 0, D = 0;
   int ard_dims = 0;
+  bool radial1 = false;  // the similarity kernel is one radial (non-periodic) term: restructured O(N^2) kernels
   int64_t n = 0, npad = 0;
   int nblk = 0;  // 128-blocks
   // device buffers
