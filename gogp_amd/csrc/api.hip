@@ -693,7 +693,8 @@ static int factorize_t(gogp_handle *h, bool eager) {
     for (int b = npanel - 1; b >= 0; --b) launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->w, h->alpha);
     const size_t vb = (size_t)npad * sizeof(double);
     for (int it = 0; it < h->refine_steps; ++it) {
-      launch_residual(sp, h->devP, h->D, h->dX, h->n, npad, h->alpha, h->dy, h->rpart, REFINE_SLABS, h->rw);
+      launch_residual(sp, h->devP, h->D, h->dX, h->n, npad, h->alpha, h->dy, h->rpart, REFINE_SLABS, h->rw,
+                      h->radial1);
       for (int b = 0; b < npanel; ++b) launch_trsv_fwd_step(sp, L, ld, Dinv, b, npanel, h->rw, h->rz);
       HIPCHK(h, hipMemcpyAsync(h->rw, h->rz, vb, hipMemcpyDeviceToDevice, sp));
       for (int b = npanel - 1; b >= 0; --b) launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->rw, h->rd);

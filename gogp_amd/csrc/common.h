@@ -156,9 +156,10 @@ void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, 
 // r = y - K v with K recomputed in fp64 on the fly (iterative refinement of alpha on the fp32 path);
 // part: nslab * npad doubles of scratch
 void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
-                     const double *v, const double *y, double *part, int nslab, double *r);
+                     const double *v, const double *y, double *part, int nslab, double *r, bool radial1 = false);
 void launch_kmatvec_share(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
-                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out);
+                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out,
+                          bool radial1 = false);
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
                   double *prior);
 

@@ -645,7 +645,7 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
     // quadratic term of the LML is y^T alpha of the refined alpha.
     for (int it = 0; it < h->refine_steps; ++it) {
       launch_kmatvec_share(sc, h->devP, h->D, h->dX, h->n, npad, h->alpha, d->rank, d->nranks, h->rpart,
-                           REFINE_SLABS, h->rw);
+                           REFINE_SLABS, h->rw, h->radial1);
       TRCHK(d->tr->allreduce(sc, h->rw, npad, &e_));
       launch_residual_from(sc, h->rw, h->dy, npad);  // rw := y - K alpha, then its local rows
       hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((lrows + 255) / 256)), dim3(256), 0, sc, h->rw,

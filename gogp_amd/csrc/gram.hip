@@ -150,6 +150,40 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
   __syncthreads();
   const long gj = c0 + tx;
   const double *cj = CjT + tx;
+  if (P.nterms == 1 && P.kind[0] != GOGP_K_PERIODIC) {  // one radial term: as in gram_kernel
+    const int rbase = __builtin_amdgcn_readfirstlane(ty) * 16;
+    const double *xr = X + (r0 + rbase) * D;
+    double s[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) s[rr] = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double il = P.inv_len[0][d];
+      const double c = cj[d * 64];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const double u = (xr[rr * D + d] - c) * il;
+        s[rr] += u * u;
+      }
+    }
+    const int kind = P.kind[0];
+    const double c0s = P.c[0];
+#pragma unroll 2
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = rbase + rr;
+      const long gi = r0 + r;
+      double k;
+      if (gi < n && gj < n) {
+        double f, dfdr2;
+        radial_eval(kind, s[rr], f, dfdr2);
+        k = 0.0 + c0s * f;
+        if (gi == gj) k += P.noise_var;
+      } else {
+        k = (gi == gj) ? 1.0 : 0.0;
+      }
+      Out[(lr0 + r) * ld + lc0 + tx] = (T)k;
+    }
+    return;
+  }
 #pragma unroll 2
   for (int rr = 0; rr < 16; ++rr) {
     const int r = ty * 16 + rr;
@@ -172,6 +206,7 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
 // for the iterative refinement of alpha on the fp32 path: K is never read back from its rounded
 // fp32 copy.  One workgroup = 64 rows x one slab of column tiles; the slabs are summed (fixed
 // order) by kmatvec_finish_kernel, which also forms r = y - K v.
+template <bool RADIAL1>
 __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restrict__ Pp,
                                                       const double *__restrict__ X, long n,
                                                       const double *__restrict__ v, long npad,
@@ -201,13 +236,48 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restric
        ++t) {
     const long c0 = (long)t * 64;
     __syncthreads();
-    for (int idx = tid; idx < 64 * D; idx += 256) {
-      const int r = idx / D, d = idx - r * D;
-      CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
-    }
+    if (!RADIAL1)
+      for (int idx = tid; idx < 64 * D; idx += 256) {
+        const int r = idx / D, d = idx - r * D;
+        CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+      }
     if (tid < 64) vj[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
     __syncthreads();
-    if (gi < n) {
+    if (RADIAL1) {
+      // one radial term: dimension loop outside, the thread's 16 columns inside; their coordinates
+      // are wave-uniform and come from X through scalar loads (see gram_kernel); same operations in
+      // the same order per pair
+      const int cbase = __builtin_amdgcn_readfirstlane(ty) * 16;
+      const double *xc = X + (c0 + cbase) * D;
+      double s[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) s[cc] = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double il = P.inv_len[0][d];
+        const double r = RiT[d * 64 + tx];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+          const double u = (r - xc[cc * D + d]) * il;
+          s[cc] += u * u;
+        }
+      }
+      if (gi < n) {
+        const int kind = P.kind[0];
+        const double cs = P.c[0];
+#pragma unroll 2
+        for (int cc = 0; cc < 16; ++cc) {
+          const int c = cbase + cc;
+          const long gj = c0 + c;
+          if (gj < n) {
+            double f, dfdr2;
+            radial_eval(kind, s[cc], f, dfdr2);
+            double k = 0.0 + cs * f;
+            if (gi == gj) k += P.noise_var;
+            acc += k * vj[c];
+          }
+        }
+      }
+    } else if (gi < n) {
       const double *ri = RiT + tx;
       for (int cc = 0; cc < 16; ++cc) {
         const int c = ty * 16 + cc;
@@ -240,12 +310,17 @@ __global__ void kmatvec_finish_kernel(const double *__restrict__ part, int nslab
 }
 
 void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
-                     int64_t npad, const double *v, const double *y, double *part, int nslab, double *r) {
+                     int64_t npad, const double *v, const double *y, double *part, int nslab, double *r,
+                     bool radial1) {
   const int ntile = (int)(npad / 64);
   const int tps = (ntile + nslab - 1) / nslab;
   const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
-  hipLaunchKernelGGL(kmatvec_kernel, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n, v,
-                     (long)npad, tps, part, 0, ntile);
+  if (radial1)
+    hipLaunchKernelGGL(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+                       v, (long)npad, tps, part, 0, ntile);
+  else
+    hipLaunchKernelGGL(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+                       v, (long)npad, tps, part, 0, ntile);
   hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
                      (long)npad, (long)n, y, r);
 }
@@ -254,14 +329,19 @@ void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *
 // sharded form of the residual -- every rank takes its share of the column tiles, the shares are
 // all-reduced.
 void launch_kmatvec_share(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
-                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out) {
+                          const double *v, int part_idx, int nparts, double *part, int nslab, double *out,
+                          bool radial1) {
   const int ntile = (int)(npad / 64);
   const int per = (ntile + nparts - 1) / nparts;
   const int t0 = std::min(ntile, part_idx * per), t1 = std::min(ntile, (part_idx + 1) * per);
   const int tps = std::max(1, (t1 - t0 + nslab - 1) / nslab);
   const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
-  hipLaunchKernelGGL(kmatvec_kernel, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n, v,
-                     (long)npad, tps, part, t0, t1);
+  if (radial1)
+    hipLaunchKernelGGL(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+                       v, (long)npad, tps, part, t0, t1);
+  else
+    hipLaunchKernelGGL(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+                       v, (long)npad, tps, part, t0, t1);
   hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
                      (long)npad, (long)n, (const double *)nullptr, out);
 }
