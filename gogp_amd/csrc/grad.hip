@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
         }
       }
       if (ARD_D > 0 && isard) {
-#pragma unroll 1
-        for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {
+#pragma unroll
+        for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {  // unrolled: ard[] stays in registers
           const int d = ard0 + q;
           if (d >= D) break;
           const double il = P.inv_len[0][d];
@@ -237,7 +237,13 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   } while (0)
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
-  else
+  else if (radial1 && ard_dims > 16) {
+    // the restructured instance is lean enough for 32 accumulators (RADIAL1_32_VGPRS, no AGPRs): half the
+    // passes, i.e. half the distance / exp work, for 17..64 ARD dimensions
+    for (int a0 = 0; a0 < ard_dims; a0 += 32)
+      hipLaunchKernelGGL((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+  } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
 #undef GOGP_LAUNCH_GR
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC, 1, nz), dim3(256), 0, s, partials, blocks, out, tl_batch.stride);
@@ -278,7 +284,11 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
   } while (0)
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
-  else
+  else if (radial1 && ard_dims > 16) {
+    for (int a0 = 0; a0 < ard_dims; a0 += 32)
+      hipLaunchKernelGGL((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+  } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL
   hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out, 0L);
