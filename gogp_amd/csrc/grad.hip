@@ -238,7 +238,7 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
   else if (radial1 && ard_dims > 16) {
-    // the restructured instance is lean enough for 32 accumulators (RADIAL1_32_VGPRS, no AGPRs): half the
+    // the restructured instance is lean enough for 32 accumulators (189 VGPRs, no AGPRs, no scratch): half the
     // passes, i.e. half the distance / exp work, for 17..64 ARD dimensions
     for (int a0 = 0; a0 < ard_dims; a0 += 32)
       hipLaunchKernelGGL((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,

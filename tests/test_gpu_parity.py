@@ -259,9 +259,10 @@ def test_full_form_gradient_at_max_ndim(gpmod, D):
 
 @pytest.mark.parametrize("D,n", [(17, 900), (24, 900), (32, 900), (33, 900), (40, 4200), (64, 4200)])
 def test_ard_gradient_many_dimensions(gpmod, D, n):
-    """ARD kernels with more than 16 length scales: the fused gradient reduction keeps 16
-    per-dimension accumulators in registers and takes one pass per 16 dimensions; n = 4200 gives
-    every workgroup several tiles.  Against the oracle, and bit-for-bit repeatable."""
+    """ARD kernels with more than 16 length scales: the fused gradient reduction keeps 16 (32 in the
+    single-radial-term instances) per-dimension accumulators in registers and takes one pass per
+    16 (32) dimensions; n = 4200 gives every workgroup several tiles.  Against the oracle, and
+    bit-for-bit repeatable."""
     from oracle.oracle import FastOracle
     rng = np.random.default_rng(100 + D)
     X, y = _data(rng, n, D)
