@@ -257,6 +257,31 @@ def test_full_form_gradient_at_max_ndim(gpmod, D):
     np.testing.assert_allclose(g2.Gradient(), grad_o[:D + 2], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize("D,n", [(24, 900), (40, 4200)])
+def test_ard_gradient_many_dimensions_two_terms(gpmod, D, n):
+    """The same with a second term (ARD-RBF + Matern-3/2): multi-term kernels take the per-pair
+    instances of the reduction (passes of 16 ARD dimensions), single-term ones the restructured
+    instances below."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(200 + D)
+    X, y = _data(rng, n, D)
+    simil = kernel.Sum([kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.Scaled(kernel.Matern32)])
+    noise = kernel.UniformNoise
+    th = np.concatenate([[1.1], np.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D)), [0.3, 1.5], [0.2]])
+    assert simil.NTheta() + 1 == th.size
+    x = np.log(th)
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    o = FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    assert abs(g.Observe(x) - lml_o) <= 1e-9 * abs(lml_o)
+    g1 = g.Gradient()
+    g.Observe(x)
+    np.testing.assert_array_equal(g1, g.Gradient())
+    assert np.abs(g1 - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
+    g.close()
+
+
 @pytest.mark.parametrize("D,n", [(17, 900), (24, 900), (32, 900), (33, 900), (40, 4200), (64, 4200)])
 def test_ard_gradient_many_dimensions(gpmod, D, n):
     """ARD kernels with more than 16 length scales: the fused gradient reduction keeps 16 (32 in the
