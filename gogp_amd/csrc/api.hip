@@ -104,10 +104,9 @@ static void drop_cand_graph(gogp_handle *h) {
   if (h->cand_graph) (void)hipGraphExecDestroy(h->cand_graph);
   h->cand_graph = nullptr;
 }
-static void free_graph_stream(gogp_handle *h) {
-  if (h->sg) (void)hipStreamDestroy(h->sg);
-  h->sg = nullptr;
-}
+// the capture / replay stream belongs to the handle's pooled stream set (streams are never destroyed,
+// see "stream sets" below): created on first use, handed on with the set
+static hipError_t graph_stream(gogp_handle *h);
 
 static void free_cand_buffers(gogp_handle *h) {
   drop_cand_graph(h);
@@ -142,6 +141,7 @@ struct StreamSet {
   int device = -1;
   bool in_use = false;
   hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr;
+  hipStream_t sg = nullptr;  // capture / replay stream of the candidates' hipGraph, created on first use
 };
 static std::mutex g_pool_mutex;
 static std::vector<StreamSet *> g_stream_pool;
@@ -195,10 +195,21 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
   return hipSuccess;
 }
 
+static hipError_t graph_stream(gogp_handle *h) {
+  StreamSet *ss = static_cast<StreamSet *>(h->stream_set);
+  if (!ss->sg) {
+    const hipError_t e = hipStreamCreateWithFlags(&ss->sg, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  h->sg = ss->sg;
+  return hipSuccess;
+}
+
 static void release_streams(gogp_handle *h) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   if (h->stream_set) static_cast<StreamSet *>(h->stream_set)->in_use = false;
   h->stream_set = nullptr;
+  h->sg = nullptr;
   h->s = h->s2 = h->sp = h->st = h->sl = nullptr;
 }
 
@@ -210,7 +221,6 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   free_n_buffers(h);
   free_m_buffers(h);
   free_cand_buffers(h);
-  free_graph_stream(h);
   (void)hipFree(h->scalars);
   (void)hipFree(h->dscr);
   (void)hipFree(h->info);
@@ -1185,7 +1195,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         // graph.  hipStreamEndCapture of this ROCm (7.0 runtime bundled with torch) recurses without
         // end on the sweep's fork / join pattern across streams, so the graph path is limited to
         // sizes where the evaluation is a single dependent chain anyway (see the caller).
-        if (!h->sg) HIPCHK(h, hipStreamCreateWithFlags(&h->sg, hipStreamNonBlocking));
+        HIPCHK(h, graph_stream(h));
         hipStream_t keep[5] = {h->s, h->sp, h->s2, h->st, h->sl};
         h->s = h->sp = h->s2 = h->st = h->sl = h->sg;
         const hipError_t eb = hipStreamBeginCapture(h->sg, hipStreamCaptureModeRelaxed);
