@@ -164,7 +164,7 @@ def main():
                          "(gogp_observe_gradient_candidates); default 8 for configs 1 and 2 (N <= 4096: one "
                          "evaluation is a latency-bound chain), 1 otherwise")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="gogp_set_option on the benchmarked handle (A/B runs), e.g. lauum_overlap=0")
+                    help="gogp_set_option on the benchmarked handle (A/B runs), e.g. superpanel=3")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300)
     args = ap.parse_args()
