@@ -882,6 +882,159 @@ __global__ void scale_kernel(double *__restrict__ a, double f, long count) {
   if (i < count) a[i] *= f;
 }
 
+// dst (rows x nb, contiguous) = src (rows x nb block of a matrix with leading dimension ld)
+template <class T>
+__global__ void copy_block_kernel(T *__restrict__ dst, const T *__restrict__ src, long ld, int nb, long rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nb) return;
+  const long r = i / nb;
+  const int c = (int)(i - r * nb);
+  dst[i] = src[r * ld + c];
+}
+// W (rows x nb) = Ks block - U block - sum of nrecv received partial blocks (U and the partials fp64)
+template <class T>
+__global__ void residual_block_kernel(T *__restrict__ W, const T *__restrict__ Ks, const double *__restrict__ U,
+                                      long ld, const double *__restrict__ recv, int nrecv, int nb, long rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nb) return;
+  const long r = i / nb;
+  const int c = (int)(i - r * nb);
+  double u = U[r * ld + c];
+  for (int k = 0; k < nrecv; ++k) u += recv[(long)k * rows * nb + i];
+  W[i] = (T)((double)Ks[r * ld + c] - u);
+}
+__global__ void add_vec_kernel(double *__restrict__ a, const double *__restrict__ b, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) a[i] += b[i];
+}
+
+// Float shards: V = L^-1 Kstar by a distributed blocked forward substitution with the float L tiles
+// and the (fp64-computed) tile inverses, instead of V = Y^T Kstar with the explicit fp32 inverse --
+// sigma^2 = prior - |V|^2 cancels, and the substitution's error does not grow with cond(L).
+// Right-looking over block columns Q.  Every rank keeps U^T (mpad x local rows): the part of
+// sum_{Q' < I} L[I, Q'] V_Q' that its own tile columns contribute -- ACCUMULATED IN FP64 (the float
+// tiles and V_Q are widened per step and multiplied on the fp64 tile kernel): the single-GPU path
+// updates its residual in place, so every rounding is relative to the shrinking residual; a sum kept
+// apart from Kstar must not be rounded relative to its own (Kstar-sized) magnitude, or
+// W_Q = Kstar_Q - sum loses what the cancellation in sigma^2 needs (measured: sigma 1e-2 with a float
+// sum, the level of the explicit inverse).  Step Q:
+//   a. the ranks of process row Q mod Pr send their block Q of U to the owner of tile (Q, Q), which
+//      forms W_Q = Kstar_Q - sum U and V_Q = inv(L_QQ) W_Q (one GEMM with the replicated inverse)
+//      and adds |V_Q[:, j]|^2 to q_j;
+//   b. the owner sends V_Q to the other ranks of process column Q mod Pc;
+//   c. those ranks add L[I, Q] V_Q to U for their tile rows I > Q (one GEMM).
+// qsum (mpad doubles, zeroed by the caller) receives this rank's share of q; the caller all-reduces it.
+template <class T>
+static int produce_v_by_substitution(gogp_handle *h, Dist2D *d, const T *KsT, int64_t lrows, int64_t mpad, int64_t m,
+                                     double *qsum, double *qtmp, hipStream_t s, hipStream_t sc) {
+  const int nb = d->nb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc, mloc = d->mloc, NB = d->NB;
+  const size_t nb2 = (size_t)nb * nb, blk = (size_t)mpad * nb;
+  const int mt = (int)(mpad / TILE);
+  T *Wq = nullptr, *Vq = nullptr;
+  double *UT = nullptr, *recv = nullptr, *sendb = nullptr, *Vd = nullptr, *Ld = nullptr;
+  auto cleanup = [&]() {
+    for (T *p : {Wq, Vq}) (void)hipFree(p);
+    for (double *p : {UT, recv, sendb, Vd, Ld}) (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc(&UT, (size_t)mpad * lrows * sizeof(double) + 16);
+  if (e == hipSuccess) e = hipMalloc(&Wq, blk * sizeof(T) + 16);
+  if (e == hipSuccess) e = hipMalloc(&Vq, blk * sizeof(T) + 16);
+  if (e == hipSuccess) e = hipMalloc(&recv, blk * (size_t)std::max(1, Pc - 1) * sizeof(double) + 16);
+  if (e == hipSuccess) e = hipMalloc(&sendb, blk * sizeof(double) + 16);
+  if (e == hipSuccess) e = hipMalloc(&Vd, blk * sizeof(double) + 16);
+  if (e == hipSuccess) e = hipMalloc(&Ld, (size_t)mloc * nb2 * sizeof(double) + 16);
+  if (e == hipSuccess) e = hipMemsetAsync(UT, 0, (size_t)mpad * lrows * sizeof(double), s);
+  if (e != hipSuccess) {
+    cleanup();
+    (void)hipGetLastError();
+    return fail(h, GOGP_ENOMEM, "Produce: out of device memory");
+  }
+  const T *Dinv = d->mat<T>(d->Dinv);
+  const unsigned cb = (unsigned)((blk + 255) / 256);
+  std::vector<XferOp> ops;
+  std::string terr;
+  int rc = GOGP_OK;
+  for (int Q = 0; Q < NB && rc == GOGP_OK; ++Q) {
+    const int kr = Q % Pr, kc = Q % Pc;
+    const bool in_row = pr == kr, in_col = pc == kc, owner = in_row && in_col;
+    const int bi = Q / Pr, bj = Q / Pc;
+    // ---- a. partial sums of block Q to the owner
+    ops.clear();
+    if (in_row && !owner) {
+      hipLaunchKernelGGL(copy_block_kernel<double>, dim3(cb), dim3(256), 0, s, sendb, UT + (size_t)bi * nb,
+                         (long)lrows, nb, (long)mpad);
+      rec(h, E(Q, 0), s);
+      wait(h, sc, E(Q, 0));
+      ops.push_back(xop<double>(d->rank_of(pr, kc), true, sendb, (int64_t)blk));
+    } else if (owner) {
+      int k = 0;
+      for (int c = 0; c < Pc; ++c)
+        if (c != kc) ops.push_back(xop<double>(d->rank_of(pr, c), false, recv + (size_t)(k++) * blk, (int64_t)blk));
+    }
+    rc = d->tr->group(sc, ops, &terr);
+    if (rc != GOGP_OK) break;
+    if (in_row && !owner) {  // sendb is packed again at a later step: not before this send is through
+      rec(h, E(Q, 5), sc);
+      wait(h, s, E(Q, 5));
+    }
+    if (owner) {
+      rec(h, E(Q, 1), sc);
+      wait(h, s, E(Q, 1));
+      hipLaunchKernelGGL(residual_block_kernel<T>, dim3(cb), dim3(256), 0, s, Wq, KsT + (size_t)bi * nb,
+                         UT + (size_t)bi * nb, (long)lrows, recv, Pc - 1, nb, (long)mpad);
+      // V_Q^T (mpad x nb) = W_Q^T inv(L_QQ)^T
+      launch_gemm_nt(s, GEMM_RECT, mt, d->tpb, nb, 1.0, Wq, nb, Dinv + (size_t)Q * nb2, nb, 0.0, Vq, nb, nullptr);
+      launch_rownorm_dot(s, Vq, nb, nullptr, nb, m, nullptr, qtmp);
+      hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, qsum, qtmp, (long)m);
+      rec(h, E(Q, 2), s);
+      wait(h, sc, E(Q, 2));
+    }
+    // ---- b. V_Q down the process column
+    ops.clear();
+    if (owner) {
+      for (int r2 = 0; r2 < Pr; ++r2)
+        if (r2 != pr) ops.push_back(xop<T>(d->rank_of(r2, pc), true, Vq, (int64_t)blk));
+    } else if (in_col) {
+      ops.push_back(xop<T>(d->rank_of(kr, kc), false, Vq, (int64_t)blk));
+    }
+    rc = d->tr->group(sc, ops, &terr);
+    if (rc != GOGP_OK) break;
+    if (owner && Pr > 1) {  // Vq is written again (on s) when this rank owns a later step
+      rec(h, E(Q, 6), sc);
+      wait(h, s, E(Q, 6));
+    }
+    // ---- c. U[I] += L[I, Q] V_Q for my tile rows I > Q
+    if (in_col) {
+      const int bi0 = first_gt(Q, pr, Pr);
+      if (!owner) {
+        rec(h, E(Q, 3), sc);
+        wait(h, s, E(Q, 3));
+      }
+      if (bi0 < mloc) {
+        launch_convert_block(s, Vq, nb, Vd, nb, (int)mpad, nb);
+        launch_convert_block(s, d->lchunk<T>(bj) + (size_t)bi0 * nb2, nb, Ld, nb, (mloc - bi0) * nb, nb);
+        launch_dgemm_nt(s, GEMM_RECT, mt, (mloc - bi0) * d->tpb, nb, 1.0, Vd, nb, Ld, nb, 1.0, UT + (size_t)bi0 * nb,
+                        lrows, nullptr);
+      }
+      // Vq / sendb are reused by the next step: its transfers wait for this update
+      rec(h, E(Q, 4), s);
+      wait(h, sc, E(Q, 4));
+    }
+  }
+  if (rc != GOGP_OK) {
+    (void)hipStreamSynchronize(sc);
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    h->err = "sharded Produce: " + terr;
+    return rc;
+  }
+  e = hipStreamSynchronize(sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  cleanup();
+  HIPCHK(h, e);
+  return GOGP_OK;
+}
+
 template <class T>
 static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
   Dist2D *d = h->dist;
@@ -909,13 +1062,16 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
   PMALLOC(Xloc, lrows * h->D);
   PMALLOC(aloc, lrows);
   PMALLOC(Ks, mpad * lrows);
-  PMALLOC(Yt, (int64_t)nb * lrows);
-  PMALLOC(Vt, mpad * lcols);
-  if (Pr > 1) PMALLOC(Vr, (int64_t)(Pr - 1) * mpad * lcols);
-  PMALLOC(vec, 4 * mpad);
-  double *prior = vec, *red2 = vec + mpad /* [mu | q] */, *dsig = vec + 3 * mpad;
+  const bool by_substitution = sizeof(T) == 4;  // float shards: see produce_v_by_substitution
+  if (!by_substitution) {
+    PMALLOC(Yt, (int64_t)nb * lrows);
+    PMALLOC(Vt, mpad * lcols);
+    if (Pr > 1) PMALLOC(Vr, (int64_t)(Pr - 1) * mpad * lcols);
+  }
+  PMALLOC(vec, 5 * mpad);
+  double *prior = vec, *red2 = vec + mpad /* [mu | q] */, *dsig = vec + 3 * mpad, *qtmp = vec + 4 * mpad;
   hipError_t e = hipMemcpyAsync(dZ, Z, (size_t)m * h->D * sizeof(double), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemsetAsync(Vt, 0, (size_t)mpad * lcols * sizeof(T), s);
+  if (e == hipSuccess && !by_substitution) e = hipMemsetAsync(Vt, 0, (size_t)mpad * lcols * sizeof(T), s);
   if (e == hipSuccess) e = hipMemsetAsync(red2, 0, (size_t)2 * mpad * sizeof(double), s);
   if (e != hipSuccess) {
     cleanup();
@@ -941,7 +1097,14 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, s, red2, 1.0 / Pc,
                        (long)mpad);
   const int mt = (int)(mpad / TILE);
-  for (int bj = 0; bj < nloc; ++bj) {
+  if constexpr (sizeof(T) == 4) {
+    const int rcs = produce_v_by_substitution<T>(h, d, Ks, lrows, mpad, m, red2 + mpad, qtmp, s, sc);
+    if (rcs != GOGP_OK) {
+      cleanup();
+      return rcs;
+    }
+  }
+  for (int bj = 0; !by_substitution && bj < nloc; ++bj) {
     const int P = bj * Pc + pc;
     const int bi0 = first_gt(P, pr, Pr);
     if (bi0 <= 0) continue;
@@ -953,7 +1116,7 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
   }
   // add the partial sums of the other ranks of my process column
   std::vector<XferOp> ops;
-  if (Pr > 1) {
+  if (Pr > 1 && !by_substitution) {
     rec(h, EV_W, s);
     wait(h, sc, EV_W);
     int k = 0;
@@ -978,8 +1141,8 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
                          (long)(mpad * lcols));
   }
   // |V_j|^2 over my tile columns; every rank of a process column holds the same sums
-  launch_rownorm_dot(s, Vt, lcols, nullptr, lcols, m, nullptr, red2 + mpad);
-  if (Pr > 1)
+  if (!by_substitution) launch_rownorm_dot(s, Vt, lcols, nullptr, lcols, m, nullptr, red2 + mpad);
+  if (Pr > 1 && !by_substitution)
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, s, red2 + mpad,
                        1.0 / Pr, (long)mpad);
   rec(h, EV_W, s);

@@ -80,12 +80,11 @@ while time.time() < t_end:
         if prec == 64:
             tol = (1e-9, 1e-7, 1e-6, 1e-5)
         else:  # no worse than 3x the single-GPU fp32 path on the same matrix (+ a rounding floor)
-            # for LML and gradient; Produce differs between the paths (V = Y^T Kstar with the explicit fp32
-            # inverse here, a blocked solve with L there) and sigma^2 = prior - |V|^2 cancels heavily for dense
-            # 1-D inputs: measured up to 5e-3 here against 2e-4 there -- fixed loose bounds for mu, sigma
+            # for the gradient; Produce on float shards is a distributed substitution with fp64-accumulated
+            # partial sums (dist2d.hip), as accurate as the single-GPU fp32 path: 10x its error + 1e-3
             # (the log-determinant's fp32 rounding path differs as well: measured 0.4x .. 5x the single-GPU
             # error on the same matrix, identical on every grid)
-            tol = (10.0 * e32["lml"] + 1e-4, 3.0 * e32["grad"] + 1e-4, 3e-2, 3e-2)
+            tol = (10.0 * e32["lml"] + 1e-4, 3.0 * e32["grad"] + 1e-4, 10.0 * e32["mu"] + 1e-3, 10.0 * e32["sigma"] + 1e-3)
         if e["lml"] > tol[0] or e["grad"] > tol[1] or e["mu"] > tol[2] or e["sigma"] > tol[3]:
             print("MISMATCH", name, n, grid, order, "precision", prec, e, "single-GPU fp32:", e32, flush=True)
             sys.exit(1)
