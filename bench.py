@@ -2,7 +2,14 @@
 """Benchmark of the hot path: GP.Observe + GP.Gradient evaluations per second.
 
     python bench.py --gpus N --steps K --warmup W [--config C]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one rank per GPU.  Started WITHOUT a launcher (no WORLD_SIZE in the environment) this
+process starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+... bench.py <same arguments>` as a CHILD -- before it has touched the GPU itself -- and relays the one
+JSON line and the exit code.  Started by a launcher it checks WORLD_SIZE == N and refuses (exit 2) on a
+mismatch: a run never silently degrades to one rank.  Every N > 1 run begins with a pre-flight of the
+transport (process group, communicator, one grouped send/recv ring, one all-reduce), each phase under a
+30 s watchdog that names rank and phase and exits non-zero.
 
 One "step" = one hyperparameters-only Observe(log theta) (Gram build + blocked
 Cholesky + forward solve + LML) followed by Gradient() (triangular inverse,
@@ -30,10 +37,14 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
                   configuration), on a bounded sample otherwise.
 """
 import argparse
+import contextlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -144,6 +155,80 @@ def pmc_traffic(config):
         return None
 
 
+def launch_ranks(ngpus, argv):
+    """`--gpus N` without a launcher: one rank per GPU through torch.distributed.run, started as a child
+    process BEFORE this process makes any GPU call (a process that has initialised the GPU must not
+    start or replace another on this pool).  The ranks inherit stdout / stderr: rank 0's JSON line is
+    this run's line; the child's exit code is this run's exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+class PhaseWatchdog:
+    """`with wd.phase("name", seconds):` -- if the block does not finish in time, say which rank is stuck
+    in which phase (stderr; rank 0 also prints a JSON line carrying the error) and end the process
+    non-zero.  The collective calls block in C with the GIL released, so the timer thread gets to run."""
+
+    def __init__(self, rank, json_out, line_holder):
+        self.rank, self.json_out, self.line_holder = rank, json_out, line_holder
+
+    def _bail(self, name, seconds):
+        msg = "rank %d: phase '%s' did not finish within %d s" % (self.rank, name, seconds)
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+        if self.rank == 0:
+            line = self.line_holder.get("line") or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
+            line["error"] = msg
+            try:
+                print(json.dumps(line), file=self.json_out, flush=True)
+            except Exception:
+                pass
+        os._exit(4)
+
+    @contextlib.contextmanager
+    def phase(self, name, seconds=30):
+        t = threading.Timer(seconds, self._bail, (name, seconds))
+        t.daemon = True
+        t.start()
+        try:
+            yield
+        finally:
+            t.cancel()
+
+
+def stub_rank_body(args, rank, world, json_out):
+    """Test double of the rank body (tests/test_bench_launcher.py, GOGP_BENCH_STUB=1): the ranks meet
+    over gloo on the CPU, rank 0 prints a line with what it saw, every rank exits with the requested
+    code.  Nothing here touches the GPU or the library."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    if rank == 0:
+        print(json.dumps({"stub": True, "n_gpus": world, "ranks_seen": seen, "gpus_arg": args.gpus,
+                          "config": args.config, "steps": args.steps, "nobs": args.nobs}),
+              file=json_out, flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    code = int(os.environ.get("GOGP_BENCH_STUB_EXIT", "0"))
+    if code and rank == int(os.environ.get("GOGP_BENCH_STUB_EXIT_RANK", "0")):
+        sys.exit(code)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,17 +252,30 @@ def main():
                     help="gogp_set_option on the benchmarked handle (A/B runs), e.g. superpanel=3")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--sharded-timeout", type=int, default=300)
+    ap.add_argument("--preflight-timeout", type=int, default=30,
+                    help="seconds per pre-flight phase of an N > 1 run before the watchdog ends it")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start the N ranks ourselves, as a child, before any GPU call
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: launched with WORLD_SIZE=%d but --gpus %d: refusing to run (the line would not "
+              "describe the run that was asked for)" % (world, args.gpus), file=sys.stderr, flush=True)
+        sys.exit(2)
     # stdout carries exactly ONE line (the JSON): whatever libraries print there (gloo's
     # connection notes, RCCL's version banner) goes to stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
     json_out = os.fdopen(json_fd, "w")
+    if os.environ.get("GOGP_BENCH_STUB"):
+        stub_rank_body(args, rank, world, json_out)
 
     import torch
     if not torch.cuda.is_available():
@@ -190,10 +288,41 @@ def main():
     from gogp_amd import configs
     from gogp_amd import dist as gd
     from gogp_amd import gp as G
-    gd.init(backend, torch.device("cuda", local_rank))
+    out_holder = {"line": None}
+    pw = PhaseWatchdog(rank, json_out, out_holder)
+    with pw.phase("process group init (%s)" % backend, max(args.preflight_timeout, 60)):
+        gd.init(backend, torch.device("cuda", local_rank))
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     wl = configs.workload(args.config, args.nobs, args.ndim)
+    # ---- N > 1: pre-flight of the transport the sharded evaluation uses, before anything is timed -----
+    preflight = None
+    if world > 1:
+        from gogp_amd.sharded import ShardedGP
+        Xp, yp = wl.inputs()
+        Xp, yp = Xp[:64], yp[:64]
+        tp0 = time.perf_counter()
+        with pw.phase("communicator init (unique id broadcast + ncclCommInitRank)", args.preflight_timeout):
+            sgp = ShardedGP(wl.D, wl.simil, wl.noise, X=Xp, Y=yp, device=local_rank)
+        tp1 = time.perf_counter()
+        with pw.phase("grouped send/recv ring (rank -> rank+1)", args.preflight_timeout):
+            sgp.selftest(0)
+        tp2 = time.perf_counter()
+        with pw.phase("all-reduce", args.preflight_timeout):
+            sgp.selftest(1)
+        tp3 = time.perf_counter()
+        with pw.phase("first sharded evaluation (N = 64)", args.preflight_timeout):
+            sgp.Observe(wl.log_theta(0))
+            sgp.Gradient()
+        nranks_comm, is_rccl = sgp.comm_ranks()
+        preflight = {"comm_ranks": nranks_comm, "rccl": is_rccl, "transport": sgp.transport_text(),
+                     "grid": sgp.grid_text(), "comm_init_s": tp1 - tp0, "ring_s": tp2 - tp1,
+                     "allreduce_s": tp3 - tp2, "first_eval_s": time.perf_counter() - tp3}
+        if nranks_comm != world:
+            print("bench.py: rank %d: the communicator counts %d ranks, the launcher %d" % (rank, nranks_comm, world),
+                  file=sys.stderr, flush=True)
+            os._exit(5)
+        sgp.close()
     N, D = wl.N, wl.D
     big = N > 20000
     steps = args.steps if args.steps is not None else (3 if N > 40000 else 5 if big else 10 if N > 6000 else 50)
@@ -219,11 +348,8 @@ def main():
     # Watchdog for everything that involves a collective on a path that cannot be rehearsed on
     # real multi-GPU RCCL before the driver runs it: if it hangs, rank 0 prints what it has
     # and EVERY rank exits non-zero, so the driver records the hang as a failure.
-    out_holder = {"line": None}
     wd = None
     if world > 1:
-        import threading
-
         def _bail():
             if rank == 0:
                 line = out_holder["line"] or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
@@ -237,6 +363,7 @@ def main():
 
     out = None
     g = None
+    lbfgs_sharded = None
     if not sharded_value:
         g = G.GP(D, simil, noise, device=local_rank, precision=prec)
         for ov in args.option:
@@ -304,6 +431,24 @@ def main():
         par_text = "ONE evaluation sharded 2-D block-cyclically over a %s grid of GPUs (%s)" % (
             sg.grid_text(), sg.transport_text())
         scaling = "strong"
+        if not args.no_produce:
+            # configs[4]: "LML+grad inside L-BFGS hyperparameter loop" -- the optimiser over the SHARDED
+            # handle: every rank runs the same (deterministic) iteration on the same all-reduced LML and
+            # gradient, so the ranks stay in step without any extra exchange
+            from gogp_amd import optimize
+            iters = 2 if N > 40000 else 4
+            sync()
+            tl = time.perf_counter()
+            try:
+                res = optimize.lbfgs(sg, wl.log_theta(0), major_iterations=iters, gradient_threshold=1e-9)
+                sync()
+                tl = time.perf_counter() - tl
+                lbfgs_sharded = {
+                    "major_iterations": res.iterations, "evaluations": res.evaluations, "seconds": tl,
+                    "evals_per_s": res.evaluations / tl, "lml_start": res.history[0], "lml_end": res.lml,
+                    "note": "optimize.lbfgs over the sharded handle, the same iterate sequence on every rank"}
+            except Exception as e:  # noqa: BLE001
+                lbfgs_sharded = {"error": repr(e)[:200]}
 
     if rank == 0:
         algo_flops_step = float(N) ** 3 * cps  # N^3/3 Cholesky + 2N^3/3 inverse per evaluation
@@ -338,6 +483,8 @@ def main():
                 "parallelism": par_text,
             },
             "lml": lml,
+            "rccl_ranks": (preflight["comm_ranks"] if preflight and preflight["rccl"] else None),
+            "preflight": preflight,
             "roofline": {
                 "bound": "mfma",
                 "kernel": ("gogp::sgemm_nt_kernel (v_mfma_f32_32x32x2_f32 GEMM/SYRK tile kernel)" if prec == 32 else
@@ -548,6 +695,8 @@ def main():
         wd.cancel()
 
     if rank == 0:
+        if lbfgs_sharded is not None:
+            out["lbfgs_loop"] = lbfgs_sharded
         if sharded is not None:
             out["sharded_evaluation"] = sharded
         if world == 1 and not args.no_cpu_baseline:

@@ -69,8 +69,12 @@ SYMBOLS = [
      [_h, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
       ctypes.c_void_p]),
     ("gogp_dist_local_bytes", _i64, [_h]),
+    ("gogp_dist_comm_ranks", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_int)]),
+    ("gogp_dist_selftest", ctypes.c_int, [_h, ctypes.c_int, _i64]),
     ("gogp_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("gogp_profile_read", ctypes.c_int, [_h, _dp, ctypes.POINTER(_i64), _dp, _dp]),
+    ("gogp_profile_read_launches", ctypes.c_int,
+     [_h, _i64, _dp, _dp, _dp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     ("gogp_profile_read_aux", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.POINTER(_i64)]),
     ("gogp_set_option", ctypes.c_int, [_h, ctypes.c_char_p, _i64]),
     ("gogp_version", ctypes.c_char_p, []),

@@ -140,8 +140,9 @@ static void free_m_buffers(gogp_handle *h) {
 struct StreamSet {
   int device = -1;
   bool in_use = false;
-  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr;
+  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr, sk = nullptr;
   hipStream_t sg = nullptr;  // capture / replay stream of the candidates' hipGraph, created on first use
+  hipStream_t s2_low = nullptr, st_low = nullptr;  // option "inv_prio": low-priority twins, created on first use
 };
 static std::mutex g_pool_mutex;
 static std::vector<StreamSet *> g_stream_pool;
@@ -162,6 +163,8 @@ static hipError_t create_stream_set(StreamSet *ss, int device) {
     e = hipStreamCreateWithPriority(&ss->sp, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->st, hipStreamNonBlocking, normal);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sl, hipStreamNonBlocking, normal);
+    // K^-1 accumulates behind everything else: whatever the chains leave idle
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sk, hipStreamNonBlocking, least);
   }
   return e;
 }
@@ -178,7 +181,7 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
     ss = new StreamSet();
     const hipError_t e = create_stream_set(ss, device);
     if (e != hipSuccess) {  // partial sets are not pooled
-      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl})
+      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl, ss->sk})
         if (q) (void)hipStreamDestroy(q);
       delete ss;
       return e;
@@ -192,6 +195,26 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
   h->sp = ss->sp;
   h->st = ss->st;
   h->sl = ss->sl;
+  h->sk = ss->sk;
+  return hipSuccess;
+}
+
+// option "inv_prio": the streams of the triangular inverse at low priority (twins of s2 / st in the
+// handle's pooled set, created on first use)
+static hipError_t apply_inv_prio(gogp_handle *h) {
+  StreamSet *ss = static_cast<StreamSet *>(h->stream_set);
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (h->inv_prio >= 1 && !ss->s2_low) {
+    const hipError_t e = hipStreamCreateWithPriority(&ss->s2_low, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return e;
+  }
+  if (h->inv_prio >= 2 && !ss->st_low) {
+    const hipError_t e = hipStreamCreateWithPriority(&ss->st_low, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return e;
+  }
+  h->s2 = h->inv_prio >= 1 ? ss->s2_low : ss->s2;
+  h->st = h->inv_prio >= 2 ? ss->st_low : ss->st;
   return hipSuccess;
 }
 
@@ -210,7 +233,7 @@ static void release_streams(gogp_handle *h) {
   if (h->stream_set) static_cast<StreamSet *>(h->stream_set)->in_use = false;
   h->stream_set = nullptr;
   h->sg = nullptr;
-  h->s = h->s2 = h->sp = h->st = h->sl = nullptr;
+  h->s = h->s2 = h->sp = h->st = h->sl = h->sk = nullptr;
 }
 
 extern "C" void gogp_destroy(gogp_handle *h) {
@@ -232,7 +255,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   for (auto &pool : h->aux_ev)
     for (auto e : pool) (void)hipEventDestroy(e);
   for (auto e : h->evs) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl})
+  for (hipStream_t q : work_streams(h))
     if (q) (void)hipStreamSynchronize(q);
   release_streams(h);
   delete h;
@@ -329,8 +352,8 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   HIPCHK(h, hipSetDevice(h->device));
   // nothing of a previous evaluation may still be running when buffers are
   // replaced or re-filled
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
-  h->trtri_pending = h->alpha_pending = false;
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
   if (h->dist) {
     const int rcs = gogp_dist_sync(h);
     if (rcs != GOGP_OK) return rcs;
@@ -574,10 +597,17 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipStreamWaitEvent(sp, ev(h, EV_TRTRI), 0);
     h->trtri_pending = false;
   }
+  if (h->kinv_pending) {
+    // ... and K^-1 accumulating in bufA
+    (void)hipStreamWaitEvent(s, ev(h, EV_KINV), 0);
+    (void)hipStreamWaitEvent(sp, ev(h, EV_KINV), 0);
+    h->kinv_pending = false;
+  }
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
   h->trtri_done = false;
   h->notpd = -1;
+  const bool fuse_kinv = eager && h->kinv_fused;
   int rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
   if (eager) {
@@ -682,7 +712,24 @@ static int factorize_t(gogp_handle *h, bool eager) {
     if (eager) {
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
       trtri_superstep<T>(h, P0, nsub, st, s2);
+      if (fuse_kinv) {
+        // ---- and K^-1 = Y Y^T = sum over the column panels of Y, right behind: the rank-(nsub*256)
+        // update K^-1[0:CE, 0:CE] (+)= Y[0:CE, C0:CE] Y[0:CE, C0:CE]^T on the lower tiles (block rows
+        // C0.. are new: overwritten).  That corner of bufA is dead (panels < CE of L are final) and
+        // disjoint from R.  The updates wait for nothing but their panel of Y and grow towards the
+        // end of the sweep, where the two chains leave most of the GPU idle: lowest priority.
+        (void)hipStreamWaitEvent(h->sk, ev(h, EV_BASE + 4 * P0 + 2), 0);
+        GemmGrid gk;
+        gk.new_row0 = (int)(C0 / TILE);
+        const T *Yp = reinterpret_cast<const T *>(h->bufY) + C0;
+        launch_gemm_nt(h->sk, GEMM_LOWER, (int)(CE / TILE), (int)(CE / TILE), CE - C0, 1.0, Yp, ld, Yp, ld,
+                       1.0, A, ld, pf, &gk);
+      }
     }
+  }
+  if (fuse_kinv) {
+    (void)hipEventRecord(ev(h, EV_KINV), h->sk);
+    h->kinv_pending = true;
   }
   if (eager) {
     (void)hipEventRecord(ev(h, EV_TRTRI), st);
@@ -746,7 +793,8 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(s2);
     (void)hipStreamSynchronize(h->sl);
-    h->alpha_pending = false;
+    (void)hipStreamSynchronize(h->sk);
+    h->alpha_pending = h->kinv_pending = false;
     h->trtri_done = h->trtri_pending = false;
     h->notpd = fr.notpd;
     h->err = fr.msg;
@@ -874,6 +922,14 @@ static int compute_kinv_t(gogp_handle *h) {
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
   GemmProfile *pf = &h->prof;
+  if (h->kinv_pending) {
+    // the fused sweep accumulated K^-1 behind the triangular inverse (factorize_t): nothing to launch
+    (void)hipStreamWaitEvent(s, ev(h, EV_KINV), 0);
+    if (h->trtri_pending) (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+    h->kinv_pending = h->trtri_pending = false;
+    h->have_kinv = true;
+    return GOGP_OK;
+  }
   if (!h->trtri_done) {
     // lazy path: the triangular inverse was not fused into the factorisation
     hipStream_t sp = h->lookahead ? h->sp : h->s;
@@ -1048,6 +1104,7 @@ static CandLayout cand_layout(int64_t npad) {
 
 static int ensure_candidates(gogp_handle *h, int k) {
   if (k > h->cand_host_k) {
+    drop_cand_graph(h);  // the captured graph copies from / to these pinned blocks
     (void)hipHostFree(h->cand_hostP);
     (void)hipHostFree(h->cand_hscal);
     h->cand_hostP = nullptr;
@@ -1059,6 +1116,9 @@ static int ensure_candidates(gogp_handle *h, int k) {
     h->cand_host_k = k;
   }
   if (k > h->cand_cap_k || h->npad > h->cand_cap_npad) {
+    // a captured graph holds raw pointers into the arena at the OLD stride: a new arena may come back
+    // at the same address with another slot size, which the pointer comparison alone would not notice
+    drop_cand_graph(h);
     (void)hipFree(h->cand_arena);
     h->cand_arena = nullptr;
     h->cand_cap_k = 0;
@@ -1093,8 +1153,9 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   }
   HIPCHK(h, hipSetDevice(h->device));
   // nothing of the handle's own evaluation may still be running: its streams and events are reused
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
-  h->trtri_pending = h->alpha_pending = false;
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+  if (h->kinv_pending) h->have_kinv = true;  // the handle's own K^-1 finished accumulating
+  h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
   int rc = ensure_candidates(h, k);
   if (rc != GOGP_OK) return rc;
 
@@ -1164,7 +1225,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
     // every stream joins the main one (the end of a captured graph; harmless otherwise)
     size_t slot = EV_BASE + 4 * (size_t)(h->npad / PANEL);  // the four event slots behind the panels' own
-    for (hipStream_t q : {h->sp, h->s2, h->st, h->sl}) order(h, slot++, q, h->s);
+    for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sk}) order(h, slot++, q, h->s);
     return GOGP_OK;
   };
   auto run = [&]() -> int {
@@ -1173,6 +1234,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     auto &key = h->cand_graph_key;
     auto same = [&](const decltype(h->cand_graph_key) &q) {
       return q.k == k && q.n == h->n && q.superpanel == h->superpanel && q.arena == h->cand_arena &&
+             q.stride == h->cand_stride && q.cap_npad == h->cand_cap_npad && q.kinv_fused == h->kinv_fused &&
              q.dX == h->dX && q.dy == h->dy && q.hostP == h->cand_hostP && q.hscal == h->cand_hscal;
     };
     const bool hit = graph && h->cand_graph && same(key);
@@ -1183,6 +1245,9 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     h->cand_seen_key.n = h->n;
     h->cand_seen_key.superpanel = h->superpanel;
     h->cand_seen_key.arena = h->cand_arena;
+    h->cand_seen_key.stride = h->cand_stride;
+    h->cand_seen_key.cap_npad = h->cand_cap_npad;
+    h->cand_seen_key.kinv_fused = h->kinv_fused;
     h->cand_seen_key.dX = h->dX;
     h->cand_seen_key.dy = h->dy;
     h->cand_seen_key.hostP = h->cand_hostP;
@@ -1196,8 +1261,8 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         // end on the sweep's fork / join pattern across streams, so the graph path is limited to
         // sizes where the evaluation is a single dependent chain anyway (see the caller).
         HIPCHK(h, graph_stream(h));
-        hipStream_t keep[5] = {h->s, h->sp, h->s2, h->st, h->sl};
-        h->s = h->sp = h->s2 = h->st = h->sl = h->sg;
+        hipStream_t keep[6] = {h->s, h->sp, h->s2, h->st, h->sl, h->sk};
+        h->s = h->sp = h->s2 = h->st = h->sl = h->sk = h->sg;
         const hipError_t eb = hipStreamBeginCapture(h->sg, hipStreamCaptureModeRelaxed);
         hipError_t ec = eb;
         if (eb == hipSuccess) {
@@ -1209,6 +1274,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         h->s2 = keep[2];
         h->st = keep[3];
         h->sl = keep[4];
+        h->sk = keep[5];
         if (r != GOGP_OK) {
           if (gr) (void)hipGraphDestroy(gr);
           return r;
@@ -1221,6 +1287,9 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         key.n = h->n;
         key.superpanel = h->superpanel;
         key.arena = h->cand_arena;
+        key.stride = h->cand_stride;
+        key.cap_npad = h->cand_cap_npad;
+        key.kinv_fused = h->kinv_fused;
         key.dX = h->dX;
         key.dy = h->dy;
         key.hostP = h->cand_hostP;
@@ -1232,13 +1301,13 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
       r = enqueue();
       if (r != GOGP_OK) return r;
     }
-    for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+    for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
     HIPCHK(h, hipGetLastError());
     return GOGP_OK;
   };
   rc = run();
   if (rc != GOGP_OK)  // a HIP failure: drain before the buffers change hands again
-    for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : work_streams(h)) (void)hipStreamSynchronize(q);
 
   std::string first_msg;
   int first = rc;
@@ -1292,7 +1361,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   h->with_obs = sv.with_obs;
   h->grad_valid = sv.grad_valid;
   h->trtri_done = sv.trtri_done;
-  h->trtri_pending = h->alpha_pending = false;
+  h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
   h->lml = sv.lml;
   h->cond_lb = sv.cond_lb;
   h->theta_s = sv.theta_s;
@@ -1483,8 +1552,8 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   h->observed = false;
   h->grad_valid = false;
   h->have_kinv = false;
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
-  h->trtri_done = h->trtri_pending = false;
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+  h->trtri_done = h->trtri_pending = h->kinv_pending = false;
   if (h->n == 0) return GOGP_OK;
   rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
@@ -1536,14 +1605,37 @@ extern "C" int gogp_profile_enable(gogp_handle *h, int on) {
   h->prof.used = 0;
   h->prof.flops = 0;
   h->prof.launches = 0;
+  h->prof.lflops.clear();
+  h->prof.ltag.clear();
   for (auto &u : h->aux_used) u = 0;
+  return GOGP_OK;
+}
+
+// Every launch of the tile kernel since profiling was enabled: start / end (ms since the first launch's
+// start), flops, tag = mode * 1e8 + (K / 16) * 1e5 + tiles.  Does not reset (gogp_profile_read does).
+extern "C" int gogp_profile_read_launches(gogp_handle *h, int64_t cap, double *t0_ms, double *t1_ms,
+                                          double *flops, int64_t *tag, int64_t *n) {
+  if (!h || !n) return GOGP_EARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+  const int64_t nl = (int64_t)std::min(h->prof.used / 2, h->prof.lflops.size());
+  *n = nl;
+  for (int64_t i = 0; i < nl && i < cap; ++i) {
+    float d = 0.f, a = 0.f;
+    (void)hipEventElapsedTime(&d, h->prof.pool[2 * i], h->prof.pool[2 * i + 1]);
+    (void)hipEventElapsedTime(&a, h->prof.pool[0], h->prof.pool[2 * i]);
+    if (t0_ms) t0_ms[i] = a;
+    if (t1_ms) t1_ms[i] = (double)a + d;
+    if (flops) flops[i] = h->prof.lflops[(size_t)i];
+    if (tag) tag[i] = h->prof.ltag[(size_t)i];
+  }
   return GOGP_OK;
 }
 
 extern "C" int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches) {
   if (!h || cls < 0 || cls >= GOGP_PROF_NCLASS) return GOGP_EARG;
   HIPCHK(h, hipSetDevice(h->device));
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   double sum = 0.0;
   int64_t cnt = 0;
   for (size_t i = 0; i + 1 < h->aux_used[cls]; i += 2) {
@@ -1562,7 +1654,7 @@ extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_
                                  double *gemm_flops, double *gemm_busy_ms) {
   if (!h) return GOGP_EARG;
   HIPCHK(h, hipSetDevice(h->device));
-  for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+  for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   double ms = 0.0, busy = 0.0;
   // launches run concurrently on up to four streams: besides the sum of the
   // per-launch durations report the length of the UNION of the launch intervals
@@ -1595,6 +1687,8 @@ extern "C" int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_
   h->prof.used = 0;
   h->prof.flops = 0;
   h->prof.launches = 0;
+  h->prof.lflops.clear();
+  h->prof.ltag.clear();
   return GOGP_OK;
 }
 
@@ -1618,13 +1712,25 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
       return fail(h, GOGP_EARG, "precision: set it before gogp_dist_init_* (the shard's buffers are typed)");
     if ((int)value != h->prec) {
       HIPCHK(h, hipSetDevice(h->device));
-      for (hipStream_t q : {h->s, h->sp, h->s2, h->st, h->sl}) HIPCHK(h, hipStreamSynchronize(q));
+      for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
       free_n_buffers(h);
       free_m_buffers(h);
       h->prec = (int)value;
       h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
-      h->trtri_done = h->trtri_pending = h->alpha_pending = false;
+      h->trtri_done = h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
     }
+    return GOGP_OK;
+  }
+  if (strcmp(name, "kinv_fused") == 0) {
+    h->kinv_fused = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "inv_prio") == 0) {
+    if (value < 0 || value > 2) return fail(h, GOGP_EARG, "inv_prio must be 0..2");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+    h->inv_prio = (int)value;
+    HIPCHK(h, apply_inv_prio(h));
     return GOGP_OK;
   }
   if (strcmp(name, "graph") == 0) {  // candidates: replay a captured hipGraph instead of re-enqueueing

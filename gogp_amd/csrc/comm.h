@@ -36,6 +36,9 @@ class Transport {
   virtual const char *name() const = 0;
   // true: group()/allreduce() only enqueue on `sc`; false: they return after completion
   virtual bool async() const = 0;
+  // ranks of the communicator as the transport itself counts them (RCCL: ncclCommCount)
+  virtual int comm_ranks() const = 0;
+  virtual bool is_rccl() const { return false; }
   // All transfers of one step.  Every rank calls group() for every step in the same order;
   // within a step each (sender, receiver) pair lists its transfers in the same order.
   virtual int group(hipStream_t sc, const std::vector<XferOp> &ops, std::string *err) = 0;

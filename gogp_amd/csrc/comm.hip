@@ -40,6 +40,11 @@ class RcclTransport : public Transport {
   }
   const char *name() const override { return "RCCL grouped ncclSend/ncclRecv + ncclAllReduce on the comm stream"; }
   bool async() const override { return true; }
+  bool is_rccl() const override { return true; }
+  int comm_ranks() const override {
+    int n = 0;
+    return (comm && ncclCommCount(comm, &n) == ncclSuccess) ? n : -1;
+  }
   int group(hipStream_t sc, const std::vector<XferOp> &ops, std::string *err) override {
     bool any = false;
     for (const XferOp &o : ops) any = any || o.count > 0;
@@ -84,6 +89,7 @@ class CallbackTransport : public Transport {
   gogp_exchange_fn ex = nullptr;
   gogp_allreduce_fn ar = nullptr;
   void *user = nullptr;
+  int nranks = 1;
   char *host = nullptr;  // pinned staging
   size_t host_bytes = 0;
   ~CallbackTransport() override {
@@ -91,6 +97,7 @@ class CallbackTransport : public Transport {
   }
   const char *name() const override { return "host callbacks (pinned staging, host-synchronous)"; }
   bool async() const override { return false; }
+  int comm_ranks() const override { return nranks; }
   int ensure(size_t bytes, std::string *err) {
     if (bytes <= host_bytes) return GOGP_OK;
     if (host) (void)hipHostFree(host);
@@ -179,8 +186,8 @@ class CallbackTransport : public Transport {
 Transport *make_callback_transport(int rank, int nranks, gogp_exchange_fn ex, gogp_allreduce_fn ar,
                                    void *user) {
   (void)rank;
-  (void)nranks;
   CallbackTransport *t = new CallbackTransport();
+  t->nranks = nranks;
   t->ex = ex;
   t->ar = ar;
   t->user = user;

@@ -58,6 +58,10 @@ struct GemmProfile {
   size_t used = 0;
   double flops = 0;
   int64_t launches = 0;
+  // per launch, in launch order (the events are pool[2i], pool[2i+1]): flops and a tag
+  // mode * 1e6 + tiles-across * 1e3... see gogp_profile_read_launches
+  std::vector<double> lflops;
+  std::vector<int64_t> ltag;
 };
 
 // Tile filter of the tile kernel in a sharded (2-D block-cyclic) evaluation (GemmArgs in
@@ -66,8 +70,12 @@ struct GemmProfile {
 // the Pr x Pc process grid.  rule 1: keep the tiles of the GLOBAL lower triangle; rule 2:
 // the same, and tiles of global row block beta0 overwrite C (beta = 0) while the others
 // accumulate (beta = 1): the rank-k updates of K^-1 = Y Y^T.
+// GEMM_LOWER only: new_row0 >= 0 -- tile rows ti >= new_row0 (128-tiles) overwrite C (beta = 0), the
+// rows above them accumulate with the launch's beta: the rank-k updates K^-1 (+)= Y_P Y_P^T of the
+// fused sweep (api.hip), whose newest block rows have no earlier contribution.
 struct GemmGrid {
   int rule = 0, tpb_shift = 0, rblk0 = 0, cblk0 = 0, pr = 0, Pr = 1, pc = 0, Pc = 1, beta0 = -1;
+  int new_row0 = -1;
 };
 
 // Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of

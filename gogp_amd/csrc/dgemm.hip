@@ -54,6 +54,7 @@ struct GemmArgs {
   // or gI == gJ and the tile is on/below the diagonal of that block); rule 2 additionally
   // overwrites (beta = 0) the tiles of row block gI == beta0 and accumulates into the others.
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;
+  int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     if (gI < gJ || (gI == gJ && (ti & msk) < (tj & msk))) return;
     if (g.rule == 2) beta = (gI == g.beta0) ? 0.0 : 1.0;
   }
+  if (MODE == GEMM_LOWER && ti >= g.new_row0) beta = 0.0;
   int kbeg = 0, nkt = g.nkt;
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
@@ -265,6 +267,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.rule = 0;
   g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
   g.Pr = g.Pc = 1;
+  g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
   g.bstride = tl_batch.stride;
   const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
@@ -321,6 +324,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     e1 = prof->pool[prof->used++];
     prof->flops += flops * nz;
     prof->launches += 1;
+    prof->lflops.push_back(flops * nz);
+    prof->ltag.push_back((int64_t)mode * 100000000LL + (int64_t)(K / 16) * 100000LL + (int64_t)(ntiles > 99999 ? 99999 : ntiles));
   }
   // With profiling on, the two events ride on the kernel's own dispatch packet
   // (hipExtLaunchKernelGGL: start / stop timestamps of exactly this dispatch) instead of two
@@ -343,6 +348,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     g.mt = mt * 2;
     g.nt = nt * 2;
     g.tpb_shift += 1;  // distribution blocks counted in 64-wide tiles
+    if (g.new_row0 != 0x7fffffff) g.new_row0 *= 2;
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)

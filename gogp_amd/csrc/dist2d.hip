@@ -230,6 +230,82 @@ extern "C" int gogp_dist_init_callbacks(gogp_handle *h, int rank, int nranks, in
                           make_callback_transport(rank, nranks, exchange, allreduce, user));
 }
 
+// ---- pre-flight of the transport (bench.py, tests): the two primitives of the sweep, alone ------------
+extern "C" int gogp_dist_comm_ranks(const gogp_handle *h, int *is_rccl) {
+  if (!h || !h->dist || !h->dist->tr) return -1;
+  if (is_rccl) *is_rccl = h->dist->tr->is_rccl() ? 1 : 0;
+  return h->dist->tr->comm_ranks();
+}
+
+__global__ void selftest_fill_kernel(double *p, long count, double base) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) p[i] = base + (double)(i & 1023);
+}
+
+// phase 0: ONE group holding a send to rank+1 and a receive from rank-1 (the shape of every panel
+// exchange of the sweep: grouped ncclSend / ncclRecv between peers), payload checked on the host;
+// phase 1: one all-reduce, sum checked.  Synchronises the communication stream: the caller's
+// watchdog sees a hang as a call that does not return.
+extern "C" int gogp_dist_selftest(gogp_handle *h, int phase, int64_t count) {
+  if (!h || !h->dist || !h->dist->tr) return fail(h, GOGP_ESTATE, "selftest: not a sharded handle");
+  if (count < 1 || count > (1 << 24) || phase < 0 || phase > 1) return fail(h, GOGP_EARG, "selftest: bad arguments");
+  Dist2D *d = h->dist;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int n = d->nranks, r = d->rank;
+  double *buf = nullptr;
+  HIPCHK(h, hipMalloc(&buf, (size_t)2 * count * sizeof(double)));
+  std::vector<double> host((size_t)count);
+  const unsigned nblk = (unsigned)((count + 255) / 256);
+  int rc = GOGP_OK;
+  std::string terr;
+  hipError_t e = hipSuccess;
+  char msg[200] = "";
+  if (phase == 0) {
+    hipLaunchKernelGGL(selftest_fill_kernel, dim3(nblk), dim3(256), 0, d->sc, buf, (long)count, 1000.0 * (r + 1));
+    e = hipMemsetAsync(buf + count, 0, (size_t)count * sizeof(double), d->sc);
+    if (n > 1 && e == hipSuccess) {
+      std::vector<XferOp> ops;
+      ops.push_back(XferOp{(r + 1) % n, true, buf, count});
+      ops.push_back(XferOp{(r + n - 1) % n, false, buf + count, count});
+      rc = d->tr->group(d->sc, ops, &terr);
+    }
+    if (rc == GOGP_OK && e == hipSuccess)
+      e = hipMemcpyAsync(host.data(), n > 1 ? buf + count : buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, d->sc);
+    if (rc == GOGP_OK && e == hipSuccess) e = hipStreamSynchronize(d->sc);
+    if (rc == GOGP_OK && e == hipSuccess) {
+      const double base = 1000.0 * (((r + n - 1) % n) + 1);
+      for (int64_t i = 0; i < count; ++i)
+        if (host[(size_t)i] != base + (double)(i & 1023)) {
+          snprintf(msg, sizeof msg, "selftest: send/recv ring delivered a wrong payload at element %lld (rank %d)",
+                   (long long)i, r);
+          rc = GOGP_EHIP;
+          break;
+        }
+    }
+  } else {
+    hipLaunchKernelGGL(selftest_fill_kernel, dim3(nblk), dim3(256), 0, d->sc, buf, (long)count, (double)(r + 1));
+    rc = d->tr->allreduce(d->sc, buf, count, &terr);
+    if (rc == GOGP_OK) e = hipMemcpyAsync(host.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, d->sc);
+    if (rc == GOGP_OK && e == hipSuccess) e = hipStreamSynchronize(d->sc);
+    if (rc == GOGP_OK && e == hipSuccess) {
+      const double base = 0.5 * n * (n + 1);
+      for (int64_t i = 0; i < count; ++i)
+        if (host[(size_t)i] != base + (double)n * (double)(i & 1023)) {
+          snprintf(msg, sizeof msg, "selftest: all-reduce returned a wrong sum at element %lld (rank %d)", (long long)i, r);
+          rc = GOGP_EHIP;
+          break;
+        }
+    }
+  }
+  (void)hipFree(buf);
+  if (rc != GOGP_OK) {
+    h->err = msg[0] ? std::string(msg) : "selftest: " + terr;
+    return rc;
+  }
+  HIPCHK(h, e);
+  return GOGP_OK;
+}
+
 // ---- data: sizes and buffers of this rank's shard ----------------------------------------------
 #define DMALLOC(ptr, count)                                                     \
   do {                                                                          \
@@ -425,11 +501,14 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
       rec(h, E(P, EDIAG), sp);
       wait(h, sc, E(P, EDIAG));
     }
+    // The inverse gates the panel solve and the Y panel of process COLUMN kc only: this group carries it
+    // to those Pr - 1 ranks; everybody else (Produce's substitution needs it on every rank, after the
+    // sweep) gets it with the L panel exchange below, off the critical path.
     ops.clear();
-    if (d->nranks > 1) {
+    if (Pr > 1 && in_col) {
       if (is_diag) {
-        for (int r = 0; r < d->nranks; ++r)
-          if (r != d->rank) ops.push_back(xop<T>(r, true, Dv, (int64_t)nb2));
+        for (int r2 = 0; r2 < Pr; ++r2)
+          if (r2 != pr) ops.push_back(xop<T>(d->rank_of(r2, kc), true, Dv, (int64_t)nb2));
       } else {
         ops.push_back(xop<T>(diag_rank, false, Dv, (int64_t)nb2));
       }
@@ -478,6 +557,13 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
     const int src_r = pc % Pr;  // grid row of the rank holding the tiles of my tile columns
     if (src_r != pr && nloc - bj0 > 0)
       ops.push_back(xop<T>(d->rank_of(src_r, kc), false, Lcol + (size_t)bj0 * nb2, (int64_t)(nloc - bj0) * (int64_t)nb2));
+    // the diagonal tile's inverse for the ranks outside process column kc (last in every pair's list)
+    if (is_diag) {
+      for (int r = 0; r < d->nranks; ++r)
+        if (r % Pc != kc) ops.push_back(xop<T>(r, true, Dv, (int64_t)nb2));
+    } else if (!in_col) {
+      ops.push_back(xop<T>(diag_rank, false, Dv, (int64_t)nb2));
+    }
     TRCHK(d->tr->group(sc, ops, &e_));
     if (src_r == pr && !alias)
       pack_blocks_t<T>(sc, Lcol + (size_t)bj0 * nb2, Lrow, nloc - bj0, (int64_t)nb2,

@@ -2,6 +2,7 @@
 // and dist2d.hip (2-D block-cyclic sharded evaluation).  Private to libgogp_hip.so.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -64,21 +65,28 @@ struct gogp_handle {
   hipGraphExec_t cand_graph = nullptr;
   hipStream_t sg = nullptr;     // capture / replay stream of that graph (created on first use)
   struct {
-    int k = 0, superpanel = 0;
-    int64_t n = 0;
+    int k = 0, superpanel = 0, kinv_fused = 0;
+    int64_t n = 0, cap_npad = 0;
+    size_t stride = 0;
     const void *arena = nullptr, *dX = nullptr, *dy = nullptr, *hostP = nullptr, *hscal = nullptr;
   } cand_graph_key, cand_seen_key;  // what the graph was captured for / what the last call asked for
   // sharded evaluation (gogp_dist_init_*): 2-D block-cyclic state, nullptr on a single GPU
   gogp::Dist2D *dist = nullptr;
   hipStream_t sl = nullptr;  // forward substitution steps (low priority, off the chain)
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
-  hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T (high priority)
+  hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T
+  hipStream_t sk = nullptr;  // rank-k updates K^-1 (+)= Y_P Y_P^T behind the inverse (low priority)
   void *stream_set = nullptr;  // the pooled StreamSet the five streams belong to
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
   int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
   int eager = 1;               // Observe also runs the triangular inverse (gradient
                                // preparation), interleaved with the Cholesky sweep
+  int kinv_fused = 1;          // ... and accumulates K^-1 = sum_P Y_P Y_P^T behind it, one rank-k update
+                               // per super-panel of Y (0: one LAUUM launch over the finished Y in Gradient)
+  int inv_prio = 0;            // 0: the inverse's streams at normal priority; 1: its bulk updates (s2) low;
+                               // 2: bulk and chain (s2, st) low
+  bool kinv_pending = false;   // K^-1 is being accumulated on sk (wait for EV_KINV)
   bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
   bool trtri_pending = false;  // ... and still running on st/s2 (wait for EV_TRTRI)
   bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
@@ -137,13 +145,19 @@ struct AuxTimer {
     }                                                                                  \
   } while (0)
 
+// every work stream of the handle (the communication stream of a sharded handle is dist2d's)
+static inline std::array<hipStream_t, 6> work_streams(const gogp_handle *h) {
+  return {h->s, h->sp, h->s2, h->st, h->sl, h->sk};
+}
+
 static inline int fail(gogp_handle *h, int code, const char *msg) {
   if (h) h->err = msg;
   return code;
 }
 
 // ---- cross-stream events -----------------------------------------------------------------
-enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_BASE = 8 };
+enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_KINV = 7,
+       EV_BASE = 8 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static inline hipEvent_t ev(gogp_handle *h, size_t i) {

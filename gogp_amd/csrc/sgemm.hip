@@ -41,6 +41,7 @@ struct SGemmArgs {
   int kend;
   int trap;
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;  // GemmGrid, see dgemm.hip
+  int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
 };
 
 __device__ __forceinline__ void sload16_to_lds(const float *gsrc, float *lds_wave_base) {
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
     if (gI < gJ || (gI == gJ && (ti & msk) < (tj & msk))) return;
     if (g.rule == 2) beta = (gI == g.beta0) ? 0.0f : 1.0f;
   }
+  if (MODE == GEMM_LOWER && ti >= g.new_row0) beta = 0.0f;
   int kbeg = 0, nkt = g.nkt;
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
@@ -220,6 +222,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
   g.rule = 0;
   g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
   g.Pr = g.Pc = 1;
+  g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
   if (grid && grid->rule) {
     g.rule = grid->rule;
     g.tpb_shift = grid->tpb_shift;
@@ -274,6 +277,8 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
     e1 = prof->pool[prof->used++];
     prof->flops += flops;
     prof->launches += 1;
+    prof->lflops.push_back(flops);
+    prof->ltag.push_back((int64_t)mode * 100000000LL + (int64_t)(K / 16) * 100000LL + (int64_t)(ntiles > 99999 ? 99999 : ntiles));
   }
   // With profiling on, the two events ride on the kernel's own dispatch packet
   // (hipExtLaunchKernelGGL: start / stop timestamps of exactly this dispatch) instead of two
@@ -290,6 +295,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
     g.mt = mt * 2;
     g.nt = nt * 2;
     g.tpb_shift += 1;
+    if (g.new_row0 != 0x7fffffff) g.new_row0 *= 2;
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)

@@ -76,6 +76,8 @@ class GP:
         self.ThetaNoise: List[float] = list(ThetaNoise) if ThetaNoise is not None else [0.0] * self._nn
         #: accepted for source compatibility; the device path is always parallel
         self.Parallel = Parallel
+        #: HIP device index of the handle (-1: the device current at construction)
+        self.device = int(device)
         self._h = ctypes.c_void_p()
         L = _lib.lib()
         rc = L.gogp_create(ctypes.byref(self._desc), int(device), ctypes.byref(self._h))
@@ -304,6 +306,21 @@ class GP:
         if rc not in soft or any(int(v) not in soft for v in status):
             self._check(rc if rc not in soft else _lib.GOGP_EARG)
         return lmls, grads, status
+
+    def profile_read_launches(self):
+        """Per launch of the tile kernel since profile_enable(True): arrays (start ms, end ms, flops, tag);
+        tag = mode * 1e8 + (K / 16) * 1e5 + tiles.  Call before profile_read (which resets)."""
+        L = _lib.lib()
+        n = ctypes.c_int64(0)
+        self._check(L.gogp_profile_read_launches(self._h, 0, None, None, None, None, ctypes.byref(n)))
+        k = int(n.value)
+        t0, t1, fl = np.zeros(k), np.zeros(k), np.zeros(k)
+        tag = np.zeros(k, dtype=np.int64)
+        if k:
+            self._check(L.gogp_profile_read_launches(self._h, k, _dp(t0), _dp(t1), _dp(fl),
+                                                     tag.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                     ctypes.byref(n)))
+        return t0, t1, fl, tag
 
     def profile_read_aux(self, cls: int):
         """(sum of durations ms, timed launch groups) of one O(N^2) kernel class:

@@ -25,6 +25,13 @@ from . import _lib
 from .gp import GP
 
 
+def zlib_host() -> int:
+    """A small integer that differs between hosts (crc32 of the host name)."""
+    import socket
+    import zlib
+    return zlib.crc32(socket.gethostname().encode()) & 0xFFFFFF
+
+
 class ShardedGP(GP):
     def __init__(self, *args, group=None, grid=None, transport=None, rank=None, world=None,
                  exchange=None, allreduce=None, **kw):
@@ -34,21 +41,41 @@ class ShardedGP(GP):
         process (one thread each), which is how the tests rehearse 2x4 and 4x4 grids on one GPU."""
         import torch
         import torch.distributed as dist
+        have_pg = dist.is_available() and dist.is_initialized() and exchange is None
+        backend = dist.get_backend(group) if have_pg else ("in-process" if exchange else "none")
+        nworld = dist.get_world_size(group) if have_pg else (world or 1)
+        if transport is None:
+            transport = "rccl" if backend == "nccl" else "callbacks"
+        if transport == "rccl" and nworld > 1:
+            # one process per GPU: without an explicit device every rank would sit on device 0 and
+            # ncclCommInitRank would fail (or hang) on the duplicate; bind rank -> GPU here
+            import os
+            if kw.get("device", -1) in (None, -1):
+                kw["device"] = int(os.environ.get("LOCAL_RANK", dist.get_rank(group))) % max(1, torch.cuda.device_count())
+            mine = torch.tensor([float(kw["device"]), float(zlib_host())], dtype=torch.float64,
+                                device=torch.device("cuda", int(kw["device"])) if backend == "nccl" else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(nworld)]
+            dist.all_gather(every, mine, group=group)
+            seen = {}
+            for r, t in enumerate(every):
+                key = (int(t[0].item()), int(t[1].item()))
+                if key in seen:
+                    raise ValueError("ranks %d and %d of the group share GPU %d of one host: the RCCL transport "
+                                     "needs one GPU per rank (pass device=LOCAL_RANK, or use transport="
+                                     "'callbacks' over a gloo group for rehearsals)" % (seen[key], r, key[0]))
+                seen[key] = r
         super().__init__(*args, **kw)
         self._torch, self._dist, self._group = torch, dist, group
         self._user_exchange, self._user_allreduce = exchange, allreduce
-        have_pg = dist.is_available() and dist.is_initialized() and exchange is None
         self._rank = dist.get_rank(group) if have_pg else (rank or 0)
-        self._world = dist.get_world_size(group) if have_pg else (world or 1)
-        self._backend = dist.get_backend(group) if have_pg else ("in-process" if exchange else "none")
+        self._world = nworld
+        self._backend = backend
         L = _lib.lib()
         if grid is None:
             pr, pc = ctypes.c_int(0), ctypes.c_int(0)
             self._check(L.gogp_dist_grid(self._world, ctypes.byref(pr), ctypes.byref(pc)))
             grid = (pr.value, pc.value)
         self.grid = (int(grid[0]), int(grid[1]))
-        if transport is None:
-            transport = "rccl" if self._backend == "nccl" else "callbacks"
         self.transport = transport
         self._cb_error = None
         if transport == "rccl":
@@ -58,7 +85,9 @@ class ShardedGP(GP):
                 self._check(L.gogp_dist_unique_id(buf))
                 uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             if self._world > 1:
-                dev = "cuda" if self._backend == "nccl" else "cpu"
+                dev = "cpu"
+                if self._backend == "nccl":  # on the handle's own GPU, not on device 0
+                    dev = torch.device("cuda", self.device) if self.device >= 0 else torch.device("cuda")
                 t = uid.to(dev)
                 src = dist.get_global_rank(group, 0) if group is not None else 0
                 dist.broadcast(t, src=src, group=group)
@@ -138,6 +167,17 @@ class ShardedGP(GP):
         return ("RCCL inside libgogp_hip (grouped ncclSend/ncclRecv + ncclAllReduce)"
                 if self.transport == "rccl" else
                 "host callbacks over torch.distributed (%s)" % self._backend)
+
+    def comm_ranks(self):
+        """(ranks of the communicator as the transport counts them, True for RCCL): ncclCommCount."""
+        flag = ctypes.c_int(0)
+        n = int(_lib.lib().gogp_dist_comm_ranks(self._h, ctypes.byref(flag)))
+        return n, bool(flag.value)
+
+    def selftest(self, phase: int, count: int = 1 << 16) -> None:
+        """Pre-flight of the transport (collective): phase 0 = one grouped send/recv ring, phase 1 = one
+        all-reduce; raises on a wrong payload.  A hang is for the caller's watchdog to catch."""
+        self._check(_lib.lib().gogp_dist_selftest(self._h, int(phase), int(count)))
 
     def local_bytes(self) -> int:
         """Device bytes of this rank's shard (its tiles of K / L / Y, panel buffers)."""

@@ -279,6 +279,15 @@ int gogp_dist_init_rccl(gogp_handle *h, int rank, int nranks, int prow, int pcol
 int gogp_dist_init_callbacks(gogp_handle *h, int rank, int nranks, int prow, int pcol,
                              gogp_exchange_fn exchange, gogp_allreduce_fn allreduce,
                              void *user);
+/* Ranks of the communicator as the transport itself counts them (RCCL: ncclCommCount; callbacks:
+ * nranks), *is_rccl (may be NULL) = 1 for the RCCL transport; -1 on an unsharded handle. */
+int gogp_dist_comm_ranks(const gogp_handle *h, int *is_rccl);
+/* Pre-flight of the transport, collective: phase 0 = ONE group with a send of `count` doubles to rank+1
+ * and a receive from rank-1 (the shape of every panel exchange of the sweep), phase 1 = one all-reduce of
+ * `count` doubles; payloads are checked.  Returns after the communication stream has drained, so a
+ * transport that hangs shows up as a call that does not return (bench.py runs both under a watchdog
+ * before the first sharded evaluation).  No reference counterpart. */
+int gogp_dist_selftest(gogp_handle *h, int phase, int64_t count);
 /* Device bytes this rank holds for the N-dependent state (its tiles of K / L / Y, panel
  * buffers, block inverses); 0 before gogp_set_data or on an unsharded handle. */
 int64_t gogp_dist_local_bytes(const gogp_handle *h);
@@ -295,6 +304,13 @@ int gogp_profile_enable(gogp_handle *h, int on);
  * the accumulators. */
 int gogp_profile_read(gogp_handle *h, double *gemm_ms, int64_t *gemm_launches,
                       double *gemm_flops, double *gemm_busy_ms);
+
+/* Every launch of that kernel family since gogp_profile_enable(h, 1), in launch order: start and end in
+ * ms since the first launch started, flops launched, tag = mode * 1e8 + (K / 16) * 1e5 + tiles (mode 0
+ * rectangular, 1 lower/SYRK, 2 LAUUM).  *n = number of launches (may exceed cap; cap entries are
+ * written).  The timeline behind roofline.achieved; tools/launch_timeline.py bins it. */
+int gogp_profile_read_launches(gogp_handle *h, int64_t cap, double *t0_ms, double *t1_ms, double *flops,
+                               int64_t *tag, int64_t *n);
 
 /* The same for the bandwidth-bound O(N^2) kernels: sum of the event-measured durations
  * (ms) and number of timed launch groups of one class since the last read. */

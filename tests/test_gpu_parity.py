@@ -796,6 +796,44 @@ def test_candidates_in_one_launch_sequence_match_single_calls(gpmod, n, D, name)
     g.close()
 
 
+def test_candidates_graph_survives_arena_reallocation(gpmod):
+    """The captured launch sequence holds raw pointers into the candidates' arena at ONE slot stride.
+    (k=4, n=1000) sizes the arena for npad 1024; with n=500 on the same handle (k=4, n=500) twice
+    captures a graph with that stride; k=8 at n=500 reallocates the arena with the slots of npad 512 --
+    possibly at the same address; (k=4, n=500) again must not replay the stale graph (it would write past
+    the new arena).  Reference values come from a handle that never captures (option graph = 0)."""
+    rng = np.random.default_rng(4242)
+    D = 2
+    Xb, yb = _data(rng, 1000, D)
+    Xs, ys = Xb[:500].copy(), yb[:500].copy()
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    xs8 = np.log([1.0, 0.5, 0.2])[None, :] + 0.1 * rng.normal(size=(8, 3))
+    ref = gpmod.GP(D, simil, noise, X=Xs, Y=ys)
+    ref.set_option("graph", 0)
+    want = [(ref.Observe(x), ref.Gradient()) for x in xs8]
+    ref.close()
+    g = gpmod.GP(D, simil, noise, X=Xb, Y=yb)
+    g.observe_gradient_candidates(xs8[:4])            # arena: 4 slots of npad 1024
+    g.X, g.Y = Xs, ys
+
+    def check(k):
+        lmls, grads, status = g.observe_gradient_candidates(xs8[:k])
+        assert list(status) == [0] * k
+        for c in range(k):
+            assert lmls[c] == want[c][0], (k, c)
+            np.testing.assert_array_equal(grads[c], want[c][1])
+
+    check(4)   # seen once
+    check(4)   # captured (old stride) and replayed
+    check(4)
+    check(8)   # grows the arena: smaller slots
+    check(4)   # must be re-captured, not replayed from the old arena
+    check(4)
+    check(1)
+    check(8)
+    g.close()
+
+
 def test_candidates_one_not_positive_definite(gpmod):
     """One candidate of a batch whose matrix is not positive definite: its status says so, the
     others are unaffected (each candidate works in its own arena slot)."""
@@ -818,6 +856,7 @@ def test_candidates_one_not_positive_definite(gpmod):
     g.close()
 
 
+@pytest.mark.perf
 def test_later_handles_as_fast_as_the_first(gpmod):
     """Stream sets are pooled (api.hip): a GP created after others were closed must run as
     fast as the first one.  With hipStreamDestroy + fresh streams every later handle of the
