@@ -74,10 +74,16 @@ def host_cores():
 
 def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
     """Time the oracle's fast twin on the first `sample_n` rows of the workload (the whole
-    workload when sample_n == N) and compare the GPU path with it on the same rows."""
+    workload when sample_n == N) and compare the GPU path with it on the same rows.
+
+    Every sample reports its phases (Gram pair loop, potrf, potrs, potri, gradient pair loop) and the
+    thread pools in effect.  The Cholesky factorisation is timed twice -- LAPACK's threaded dpotrf and
+    a dgemm-based blocked one (oracle.potrf_blocked) -- and the faster of the two counts: on the GPU
+    boxes (16-CPU quota on a 256-CPU host) OpenBLAS's dpotrf collapses at some sizes (N = 8192 as slow
+    as N = 16384), which made round 2's two samples disagree with the N^3 law."""
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # before the C oracle (libgomp) is loaded
-    from threadpoolctl import threadpool_limits
+    from threadpoolctl import threadpool_info, threadpool_limits
     from oracle.oracle import FastOracle, Oracle  # checker / baseline only
     threadpool_limits(limits=cores)
     N, D = wl.N, wl.D
@@ -85,18 +91,43 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
     x = wl.log_theta(0)
     Z = wl.test_points(1024 if N >= 1024 else 16)
 
-    def run(n):
-        o = FastOracle(D, wl.simil, wl.noise, block=2048)
+    def run(n, potrf="lapack", gradient=True):
+        o = FastOracle(D, wl.simil, wl.noise, block=1024, potrf=potrf)
         o.set_data(X[:n], y[:n])
         t0 = time.time()
         lml = o.Observe(x)
-        g = o.Gradient()
+        g = o.Gradient() if gradient else None
         dt = time.time() - t0
         return o, lml, g, dt
 
+    def sample(n):
+        """(oracle, lml, grad, seconds with the faster factorisation, report)"""
+        o, lml, g, dt = run(n)
+        ph = {k: round(v, 4) for k, v in o.timings.items()}
+        rep = {"n": n, "seconds_lapack_potrf": dt, "phases_s": ph}
+        secs = dt
+        if n >= 2048:
+            ob, lml_b, _, _ = run(n, potrf="blocked", gradient=False)
+            pb = ob.timings["potrf"]
+            rep["potrf_blocked_s"] = round(pb, 4)
+            rep["lml_rel_diff_blocked_vs_lapack"] = abs(lml_b - lml) / abs(lml)
+            del ob
+            if pb < o.timings["potrf"]:
+                secs = dt - o.timings["potrf"] + pb
+                rep["factorisation_counted"] = "blocked (dgemm-based)"
+            else:
+                rep["factorisation_counted"] = "LAPACK dpotrf"
+        rep["seconds"] = secs
+        flop = float(n) ** 3
+        rep["gflops"] = {"potrf_lapack": round(flop / 3 / max(o.timings["potrf"], 1e-9) / 1e9, 1),
+                         "potri": round(2 * flop / 3 / max(o.timings["potri"], 1e-9) / 1e9, 1)}
+        if "potrf_blocked_s" in rep:
+            rep["gflops"]["potrf_blocked"] = round(flop / 3 / max(rep["potrf_blocked_s"], 1e-9) / 1e9, 1)
+        return o, lml, g, secs, rep
+
     # untimed warm-up: thread pools, first-touch page-in of OpenBLAS / libgomp
     run(min(1024, sample_n))
-    o, lml, g, dt = run(sample_n)
+    o, lml, g, dt, rep = sample(sample_n)
     full = sample_n == N
     scale = (sample_n / float(N)) ** 3
     out = {
@@ -110,6 +141,10 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
                       "" if full else "; scaled by (%d/%d)^3 to N=%d" % (sample_n, N, N))),
         "measured_at_full_n": bool(full),
         "seconds": dt,
+        "detail": rep,
+        "thread_pools": [{"api": i.get("internal_api"), "threads": i.get("num_threads"),
+                          "layer": i.get("threading_layer"), "lib": os.path.basename(i.get("filepath", ""))}
+                         for i in threadpool_info()],
     }
     mu, sigma = o.Produce(Z)
     lml_gpu, g_gpu, mu_gpu, sigma_gpu = gpu_fn(X[:sample_n], y[:sample_n], x, Z)
@@ -122,9 +157,13 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
     }
     del o
     if second_sample_n and second_sample_n < sample_n:
-        _, _, _, dt2 = run(second_sample_n)
-        out["second_sample"] = {"n": second_sample_n, "seconds": dt2,
-                                "evals_per_s_scaled_to_N": (1.0 / dt2) * (second_sample_n / float(N)) ** 3}
+        _, _, _, dt2, rep2 = sample(second_sample_n)
+        ratio = (dt / dt2) / (sample_n / float(second_sample_n)) ** 3
+        out["second_sample"] = {"n": second_sample_n, "seconds": dt2, "detail": rep2,
+                                "evals_per_s_scaled_to_N": (1.0 / dt2) * (second_sample_n / float(N)) ** 3,
+                                "time_ratio_over_n3_law": ratio,
+                                "note": "time(N) / time(n) divided by (N/n)^3: 1 = the N^3 law; the O(N^3) "
+                                        "LAPACK calls run at a higher rate at the larger size (see gflops)"}
     # the reference's own algorithm (dense dK per parameter, r0 = aa^T dK, r1 = K^-1 dK:
     # gp/gp.go:476-485; 4P N^3 flop) as restated by the faithful C oracle, single thread,
     # at a size it finishes in about a second, extrapolated by its N^3 law

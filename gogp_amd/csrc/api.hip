@@ -323,7 +323,8 @@ static int ensure_n(gogp_handle *h, int64_t n) {
   if (npad > h->cap_npad) {
     free_n_buffers(h);
     const size_t nn = (size_t)npad * (size_t)npad * h->esz();  // matrices: float on the fp32 path
-    HIPCHK(h, hipMalloc(&h->dX, (size_t)npad * h->D * sizeof(double)));
+    // (+ GOGP_MAX_NDIM doubles of slack: grad.hip reads a few coordinates past the last row)
+    HIPCHK(h, hipMalloc(&h->dX, ((size_t)npad * h->D + GOGP_MAX_NDIM) * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->bufA, nn));
     HIPCHK(h, hipMalloc(&h->bufL, nn));
@@ -363,7 +364,7 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   h->have_data = true;
   if (n == 0) return GOGP_OK;
   // zero padding rows, then copy
-  HIPCHK(h, hipMemsetAsync(h->dX, 0, (size_t)h->npad * h->D * sizeof(double), h->s));
+  HIPCHK(h, hipMemsetAsync(h->dX, 0, ((size_t)h->npad * h->D + GOGP_MAX_NDIM) * sizeof(double), h->s));
   HIPCHK(h, hipMemsetAsync(h->dy, 0, (size_t)h->npad * sizeof(double), h->s));
   HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)n * h->D * sizeof(double), kind, h->s));
   HIPCHK(h, hipMemcpyAsync(h->dy, y, (size_t)n * sizeof(double), kind, h->s));
@@ -534,8 +535,20 @@ static void diag_inv_only(gogp_handle *h, hipStream_t s, const float *L, int64_t
   launch_convert_block(s, D64, PANEL, Dp, PANEL, PANEL, PANEL);
 }
 
+// Width (in 256-panels) of the super-panel that starts at panel P0: `superpanel`, or -- option
+// "superpanel_head" -- a wider one while more than `head_remaining` panels are still to come: the bulk
+// updates of the first part of the sweep then carry K = 256 * superpanel_head (fewer passes over the
+// trailing matrix, longer tiles), and the chain, which has slack while the trailing matrix is large,
+// pays for it with more work inside the super-panel; near the end the chain is the critical path and the
+// super-panels are narrow again.
+static inline int superpanel_width(const gogp_handle *h, int npanel, int P0) {
+  const int sw = (h->superpanel_head > 0 && npanel - P0 > h->head_remaining) ? h->superpanel_head : h->superpanel;
+  return (npanel - P0 < sw) ? npanel - P0 : sw;
+}
+
 template <class T>
-static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hipStream_t s2) {
+static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int next_nsub, hipStream_t st,
+                            hipStream_t s2) {
   const int64_t npad = h->npad, ld = npad;
   T *R = reinterpret_cast<T *>(h->bufA), *Y = reinterpret_cast<T *>(h->bufY),
     *L = reinterpret_cast<T *>(h->bufL);
@@ -550,9 +563,12 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
     launch_ydiag(st, Dp, Y + c0 * ld + c0, ld);
     if (c2 < CE)  // block below the diagonal inside the super-panel: part of the K range
       launch_zero_block(st, Y + c2 * ld + c0, ld, CE - c2, PANEL);
-    if (c0 > 0)
+    if (c0 > 0) {
+      GemmGrid gtri;  // Dp is lower triangular: the first tile column only needs k < 128
+      gtri.ktri = h->ktri;
       launch_gemm_nt(st, GEMM_RECT, (int)(c0 / TILE), 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0,
-                      Y + c0, ld, pf);
+                      Y + c0, ld, pf, &gtri);
+    }
     if (c2 < CE) {  // same binary grouping as the Cholesky sweep's updates inside a super-panel
       const int done = q + 1, grp = done & -done;
       const int64_t k0 = c2 - (int64_t)grp * PANEL;
@@ -566,11 +582,11 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, hipStream_t st, hi
   if (nt > 0) {
     const int64_t Kw = CE - C0;
     const int mr = (int)(CE / TILE);
-    const int ntn = nt < 2 * h->superpanel ? nt : 2 * h->superpanel;  // next super-panel's columns
+    const int ntn = nt < 2 * next_nsub ? nt : 2 * next_nsub;  // next super-panel's columns
     // The next super-step's columns stay on the CHAIN stream (as in the Cholesky sweep: no
     // event hop on the chain); they were last touched by the previous super-step's bulk update.
     if (P0 > 0 && st != s2)
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * (P0 - h->superpanel) + 3), 0);
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * prevP0 + 3), 0);
     launch_gemm_nt(st, GEMM_RECT, mr, ntn, Kw, -1.0, Y + C0, ld, L + CE * ld + C0, ld, 1.0,
                     R + CE, ld, pf);
     if (nt > ntn) {
@@ -607,7 +623,9 @@ static int factorize_t(gogp_handle *h, bool eager) {
   h->alpha_pending = false;
   h->trtri_done = false;
   h->notpd = -1;
-  const bool fuse_kinv = eager && h->kinv_fused;
+  // option "kinv_fused": -1 (default) fuses up to npad = 10240 (measured: N = 1024 .. 8192 5-10 % faster,
+  // N = 16384 1.7 % slower than one LAUUM launch over the finished Y, which runs at the longest K)
+  const bool fuse_kinv = eager && (h->kinv_fused < 0 ? npad <= 10240 : h->kinv_fused != 0);
   int rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
   if (eager) {
@@ -623,7 +641,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   {
     AuxTimer tm(h, GOGP_PROF_GRAM, s);  // the main-stream part: all but the first block columns
     launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, reinterpret_cast<T *>(h->bufA), ld,
-                            (int64_t)h->superpanel * PANEL);
+                            (int64_t)superpanel_width(h, (int)(npad / PANEL), 0) * PANEL);
   }
   (void)hipEventRecord(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
                                             // is NOT implied: consumers of columns < 512 are on sp)
@@ -638,7 +656,6 @@ static int factorize_t(gogp_handle *h, bool eager) {
   T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
-  const int SW = h->superpanel;
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
   HIPCHK(h, cand_copy_in(h, h->w, h->dy, (size_t)npad * sizeof(double), sp));
@@ -651,8 +668,10 @@ static int factorize_t(gogp_handle *h, bool eager) {
   // super-panel) runs on the panel stream with 256-wide steps; the trailing
   // matrix gets ONE rank-(SW*256) update per super-panel on the main stream
   // (next super-panel's block columns first: look-ahead).
-  for (int P0 = 0; P0 < npanel; P0 += SW) {
-    const int nsub = (npanel - P0 < SW) ? npanel - P0 : SW;
+  int prevP0 = -1;
+  for (int P0 = 0, nsub = 0; P0 < npanel; prevP0 = P0, P0 += nsub) {
+    nsub = superpanel_width(h, npanel, P0);
+    const int next_nsub = (P0 + nsub < npanel) ? superpanel_width(h, npanel, P0 + nsub) : 0;
     const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
     for (int q = 0; q < nsub; ++q) {
       const int p = P0 + q;
@@ -662,9 +681,12 @@ static int factorize_t(gogp_handle *h, bool eager) {
       diag_block(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
       const int mt2 = (int)((npad - c2) / TILE);
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
-      if (mt2 > 0)
+      if (mt2 > 0) {
+        GemmGrid gtri;  // Dp is lower triangular: the first tile column only needs k < 128
+        gtri.ktri = h->ktri;
         launch_gemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
-                        L + c2 * ld + c0, ld, pf);
+                        L + c2 * ld + c0, ld, pf, &gtri);
+      }
       // Updates inside the super-panel, grouped like a binary counter: after panel q the
       // next g = lowbit(q+1) block columns receive the LAST g panels at once (K = 256 g), each
       // column from its own diagonal block down (the blocks above belong to R of the fused
@@ -688,13 +710,13 @@ static int factorize_t(gogp_handle *h, bool eager) {
     const int mtE = (int)((npad - CE) / TILE);
     if (mtE > 0) {
       const int64_t Kw = CE - C0;
-      const int ntn = mtE < 2 * SW ? mtE : 2 * SW;
+      const int ntn = mtE < 2 * next_nsub ? mtE : 2 * next_nsub;
       // The next super-panel's block columns, each from its diagonal block down, stay on the
       // CHAIN stream: the critical path (diag -> panel solve -> these updates -> diag) then
       // never crosses streams (two event hops of ~15 us per super-panel otherwise).  They
       // only wait for the previous super-panel's bulk update of these columns, which in
       // steady state finished long ago.
-      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * (P0 - SW) + 1 : EV_GRAM), 0);
+      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * prevP0 + 1 : EV_GRAM), 0);
       // ONE trapezoid launch for all of them (rows CE.., columns CE .. CE + ntn*128, the
       // strictly upper 256-blocks -- R of the triangular inverse -- skipped): separate
       // launches would run one after the other on this in-order stream
@@ -711,7 +733,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
       (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
-      trtri_superstep<T>(h, P0, nsub, st, s2);
+      trtri_superstep<T>(h, P0, nsub, prevP0, next_nsub, st, s2);
       if (fuse_kinv) {
         // ---- and K^-1 = Y Y^T = sum over the column panels of Y, right behind: the rank-(nsub*256)
         // update K^-1[0:CE, 0:CE] (+)= Y[0:CE, C0:CE] Y[0:CE, C0:CE]^T on the lower tiles (block rows
@@ -938,8 +960,11 @@ static int compute_kinv_t(gogp_handle *h) {
     launch_zero_upper_blocks(s, reinterpret_cast<T *>(h->bufA), ld, npad);
     order(h, EV_INIT, s, sp);
     const int npanel = (int)(npad / PANEL);
-    for (int P0 = 0; P0 < npanel; P0 += h->superpanel)
-      trtri_superstep<T>(h, P0, (npanel - P0 < h->superpanel) ? npanel - P0 : h->superpanel, sp, s);
+    int prevP0 = -1;
+    for (int P0 = 0, nsub = 0; P0 < npanel; prevP0 = P0, P0 += nsub) {
+      nsub = superpanel_width(h, npanel, P0);
+      trtri_superstep<T>(h, P0, nsub, prevP0, (P0 + nsub < npanel) ? superpanel_width(h, npanel, P0 + nsub) : 0, sp, s);
+    }
     order(h, EV_TRTRI, sp, s);
     h->trtri_done = true;
   } else if (h->trtri_pending) {
@@ -1233,7 +1258,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     const bool graph = h->use_graph && !h->prof.on && h->npad <= GRAPH_MAX_NPAD;
     auto &key = h->cand_graph_key;
     auto same = [&](const decltype(h->cand_graph_key) &q) {
-      return q.k == k && q.n == h->n && q.superpanel == h->superpanel && q.arena == h->cand_arena &&
+      return q.k == k && q.n == h->n && q.superpanel == h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining && q.arena == h->cand_arena &&
              q.stride == h->cand_stride && q.cap_npad == h->cand_cap_npad && q.kinv_fused == h->kinv_fused &&
              q.dX == h->dX && q.dy == h->dy && q.hostP == h->cand_hostP && q.hscal == h->cand_hscal;
     };
@@ -1243,7 +1268,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     const bool seen = graph && same(h->cand_seen_key);
     h->cand_seen_key.k = k;
     h->cand_seen_key.n = h->n;
-    h->cand_seen_key.superpanel = h->superpanel;
+    h->cand_seen_key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
     h->cand_seen_key.arena = h->cand_arena;
     h->cand_seen_key.stride = h->cand_stride;
     h->cand_seen_key.cap_npad = h->cand_cap_npad;
@@ -1285,7 +1310,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         HIPCHK(h, ei);
         key.k = k;
         key.n = h->n;
-        key.superpanel = h->superpanel;
+        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
         key.arena = h->cand_arena;
         key.stride = h->cand_stride;
         key.cap_npad = h->cand_cap_npad;
@@ -1405,7 +1430,9 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
   for (int p = 0; p < npanel; ++p) {
     const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
     const T *Dp = Dinv + (size_t)p * PANEL * PANEL;
-    launch_gemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf);
+    GemmGrid gtri;
+    gtri.ktri = h->ktri;
+    launch_gemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf, &gtri);
     const int nt = (int)((npad - c2) / TILE);
     if (nt > 0)
       launch_gemm_nt(s, GEMM_RECT, mt, nt, PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld, 1.0,
@@ -1544,7 +1571,6 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
                                const double *alpha) {
   if (!h || !theta_simil || (h->nn > 0 && !theta_noise)) return fail(h, GOGP_EARG, "set_factor: NULL");
   if (!h->have_data) return fail(h, GOGP_ESTATE, "set_factor: no data");
-  if (h->dist) return fail(h, GOGP_ESTATE, "set_factor: not available on a sharded handle");
   if (h->n > 0 && (!Lin || !alpha)) return fail(h, GOGP_EARG, "set_factor: NULL");
   HIPCHK(h, hipSetDevice(h->device));
   int rc = set_theta_natural(h, theta_simil, theta_noise);
@@ -1555,6 +1581,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_done = h->trtri_pending = h->kinv_pending = false;
   if (h->n == 0) return GOGP_OK;
+  if (h->dist) return gogp_dist_set_factor(h, Lin, alpha);  // collective: every rank keeps its own tiles
   rc = gogp_upload_params(h);
   if (rc != GOGP_OK) return rc;
   hipStream_t s = h->s;
@@ -1721,8 +1748,22 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     }
     return GOGP_OK;
   }
-  if (strcmp(name, "kinv_fused") == 0) {
-    h->kinv_fused = value != 0;
+  if (strcmp(name, "kinv_fused") == 0) {  // -1: by size (default), 0: LAUUM in Gradient, 1: fused
+    h->kinv_fused = value < 0 ? -1 : (value != 0);
+    return GOGP_OK;
+  }
+  if (strcmp(name, "superpanel_head") == 0) {
+    if (value < 0 || value > 8) return fail(h, GOGP_EARG, "superpanel_head must be 0..8");
+    h->superpanel_head = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "head_remaining") == 0) {
+    if (value < 0) return fail(h, GOGP_EARG, "head_remaining must be >= 0");
+    h->head_remaining = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "ktri") == 0) {
+    h->ktri = value != 0;
     return GOGP_OK;
   }
   if (strcmp(name, "inv_prio") == 0) {

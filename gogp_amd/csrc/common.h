@@ -76,6 +76,9 @@ struct GemmProfile {
 struct GemmGrid {
   int rule = 0, tpb_shift = 0, rblk0 = 0, cblk0 = 0, pr = 0, Pr = 1, pc = 0, Pc = 1, beta0 = -1;
   int new_row0 = -1;
+  // GEMM_RECT: B (nt*128 x K) is lower triangular (a block inverse: the panel solves L21 = A21 inv(L11)^T):
+  // tile column tj only sums k < (tj + 1) * tile -- the rest of its rows of B is zero
+  int ktri = 0;
 };
 
 // Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of
@@ -193,6 +196,9 @@ void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, in
 void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                           double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
+void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv);  // Dinv: ld 512
+void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd, int rows,
+                          int cols);
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld);
 void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,

@@ -55,6 +55,7 @@ struct GemmArgs {
   // overwrites (beta = 0) the tiles of row block gI == beta0 and accumulates into the others.
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;
   int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
+  int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   }
   if (MODE == GEMM_LOWER && ti >= g.new_row0) beta = 0.0;
   int kbeg = 0, nkt = g.nkt;
+  if (MODE == GEMM_RECT && g.ktri) nkt = min(nkt, (tj + 1) * BT / GEMM_BK);
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
     nkt = (g.kend - kbeg) / GEMM_BK;
@@ -268,6 +270,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
   g.Pr = g.Pc = 1;
   g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
+  g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
   g.bstride = tl_batch.stride;
   const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
@@ -293,6 +296,11 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   } else if (mode == GEMM_RECT) {
     ntiles = mt * nt;
     flops = 2.0 * (double)mt * TILE * (double)nt * TILE * (double)K;
+    if (g.ktri) {
+      flops = 0;
+      for (int j = 0; j < nt; ++j)
+        flops += 2.0 * (double)mt * TILE * TILE * (double)std::min<int64_t>(K, (int64_t)(j + 1) * TILE);
+    }
     if (g.rule) {  // count the tiles the filter keeps
       const int tpb = 1 << g.tpb_shift;
       long kept = 0;

@@ -189,7 +189,14 @@ __device__ __forceinline__ void tile_update16(double *S, int i, int c, int kb, i
   for (int v = 0; v < 4; ++v) S[(i * 16 + fk + 4 * v) * SLD + c * 16 + fr] -= acc[v];
 }
 
-__device__ void potrf128_lds(double *S, double *XD, double *rinv, int tid, long grow0,
+// (inlined: as an out-of-line function -- hipcc's choice when left alone -- the call saves four VGPRs to
+// scratch, which gives the chain kernel a private segment; A/B: -DGOGP_POTRF_NOINLINE)
+#ifdef GOGP_POTRF_NOINLINE
+__device__ __noinline__ void potrf128_lds(
+#else
+__device__ __forceinline__ void potrf128_lds(
+#endif
+    double *S, double *XD, double *rinv, int tid, long grow0,
                              long nvalid, long long *info, unsigned long long *st = nullptr) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -625,6 +632,14 @@ void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double 
                      (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
                      (unsigned long long *)nullptr, 0L);
 }
+
+#ifndef GOGP_BUILD_TESTHOOKS
+void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv) {
+  hipLaunchKernelGGL((diag256_kernel<false, false, 512>), dim3(1), dim3(NT), 0, s, L, (long)ld,
+                     (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
+                     (unsigned long long *)nullptr, 0L);
+}
+#endif
 
 #ifdef GOGP_BUILD_TESTHOOKS
 // diagnostic: run the stamped build once on a device-resident 256x256 block

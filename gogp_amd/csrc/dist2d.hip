@@ -338,7 +338,8 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
     dist_free_n(d);
     const size_t nb2 = (size_t)d->nb * d->nb;
     const size_t mrows = (size_t)d->mloc * d->nb, ncols = (size_t)d->nloc * d->nb;
-    HIPCHK(h, hipMalloc(&h->dX, (size_t)npad * h->D * sizeof(double)));
+    // (+ GOGP_MAX_NDIM doubles of slack: grad.hip reads a few coordinates past the last row)
+    HIPCHK(h, hipMalloc(&h->dX, ((size_t)npad * h->D + GOGP_MAX_NDIM) * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->dy, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->z, (size_t)npad * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->alpha, (size_t)npad * sizeof(double)));
@@ -393,6 +394,20 @@ __global__ void gather_rows_kernel(const double *__restrict__ y, double *__restr
 // ---- the diagonal tile: factor + inverse of one nb x nb block on the chain stream -----------
 // Always fp64 (as the 256-blocks of the single-GPU path): Ablk (lda) in, Lblk (ld nb) and its dense
 // inverse Dv (ld nb) out; the log-determinant is accumulated from the fp64 factor.
+// Dv (ld nb) holds X00 and X11, the inverses of the two diagonal 256-blocks of a 512x512 lower
+// triangular tile whose lower-left block is L10 (ld nb): fill in X10 = -X11 L10 X00 and the zero block
+static void tile_inverse_offdiag(Dist2D *d, hipStream_t sp, const double *L10, double *Dv, GemmProfile *pf) {
+  const int nb = d->nb;
+  launch_zero_block(sp, Dv + PANEL, nb, PANEL, PANEL);
+  double *X00T = d->scr, *WT = d->scr + (size_t)PANEL * PANEL;
+  launch_transpose_sq(sp, Dv, nb, X00T, PANEL, PANEL);
+  // WT = (L10 X00)^T = X00^T L10^T
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, X00T, PANEL, L10, nb, 0.0, WT, PANEL, pf);
+  // X10 = -X11 (L10 X00) = -X11 WT^T
+  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, -1.0, Dv + (size_t)PANEL * nb + PANEL, nb, WT, PANEL, 0.0,
+                  Dv + (size_t)PANEL * nb, nb, pf);
+}
+
 static void diag_tile64(gogp_handle *h, Dist2D *d, hipStream_t sp, double *Ablk, int lda, double *Lblk,
                         double *Dv, int64_t row0) {
   const int nb = d->nb;
@@ -406,15 +421,8 @@ static void diag_tile64(gogp_handle *h, Dist2D *d, hipStream_t sp, double *Ablk,
                   Ablk + (size_t)PANEL * lda + PANEL, lda, pf);
   launch_diag256_ld512(sp, Ablk + (size_t)PANEL * lda + PANEL, lda, Lblk + (size_t)PANEL * nb + PANEL, nb,
                        Dv + (size_t)PANEL * nb + PANEL, row0 + PANEL, h->n, h->info);
-  launch_zero_block(sp, Dv + PANEL, nb, PANEL, PANEL);
   launch_zero_block(sp, Lblk + PANEL, nb, PANEL, PANEL);
-  double *X00T = d->scr, *WT = d->scr + (size_t)PANEL * PANEL;
-  launch_transpose_sq(sp, Dv, nb, X00T, PANEL, PANEL);
-  // WT = (L10 X00)^T = X00^T L10^T
-  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, 1.0, X00T, PANEL, L10, nb, 0.0, WT, PANEL, pf);
-  // X10 = -X11 (L10 X00) = -X11 WT^T
-  launch_dgemm_nt(sp, GEMM_RECT, 2, 2, PANEL, -1.0, Dv + (size_t)PANEL * nb + PANEL, nb, WT, PANEL, 0.0,
-                  Dv + (size_t)PANEL * nb, nb, pf);
+  tile_inverse_offdiag(d, sp, L10, Dv, pf);
   launch_logdet_block(sp, Lblk, nb, row0, h->n, nb, d->red + h->npad);
 }
 static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d, int bj_d, double) {
@@ -519,10 +527,13 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
     // ---- 2. panel solve --------------------------------------------------------------------
     if (in_col) {
       wait(h, sp, E(P, ED));
-      if (bi0 < mloc)
+      if (bi0 < mloc) {
+        GemmGrid gtri;  // the tile inverse is lower triangular: tile column j only sums k < (j + 1) * 128
+        gtri.ktri = h->ktri;
         launch_gemm_nt(sp, GEMM_RECT, (mloc - bi0) * tpb, tpb, nb, 1.0,
                         A + (size_t)bi0 * nb * ldA + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
-                        d->lchunk<T>(bj_d) + (size_t)bi0 * nb2, nb, pf);
+                        d->lchunk<T>(bj_d) + (size_t)bi0 * nb2, nb, pf, &gtri);
+      }
       rec(h, E(P, EPANEL), sp);
       wait(h, sc, E(P, EPANEL));
     }
@@ -623,9 +634,12 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
     if (in_col) {
       wait(h, st, E(P, ED));
       if (P >= 2) wait(h, st, E(P - 2, ERUPD));  // bulk R update of step P-2 touched column P
-      if (bim > 0)
+      if (bim > 0) {
+        GemmGrid gtri;
+        gtri.ktri = h->ktri;
         launch_gemm_nt(st, GEMM_RECT, bim * tpb, tpb, nb, 1.0, A + (size_t)bj_d * nb, ldA, Dv, nb, 0.0,
-                        d->ychunk<T>(bj_d), nb, pf);
+                        d->ychunk<T>(bj_d), nb, pf, &gtri);
+      }
       if (is_diag) launch_transpose_sq(st, Dv, nb, d->ychunk<T>(bj_d) + (size_t)bi_d * nb2, nb, nb);
       if (bi0 > 0)  // z_P += sum_I Y[I, P]^T y_I over my tile rows
         launch_chunk_tdot(st, d->ychunk<T>(bj_d), (int64_t)bi0 * nb, nb, d->yloc, d->tpart, d->red + (size_t)P * nb);
@@ -816,31 +830,76 @@ __global__ void scatter_tile_kernel(const T *__restrict__ src, int nb, double *_
   }
 }
 
+// Collective agreement before a large collective: every rank contributes its own failure flag; if any
+// rank failed (an allocation, a bad argument) ALL return the error instead of some of them blocking in the
+// all-reduce that the failed rank never enters.  `flag`: 0 = fine.
+static int agree_ok(gogp_handle *h, Dist2D *d, int flag, const char *what) {
+  double *dflag = d->red;  // >= 1 double once data are set
+  double hf = (double)(flag != 0);
+  std::string terr;
+  hipError_t e = hipMemcpyAsync(dflag, &hf, sizeof(double), hipMemcpyHostToDevice, d->sc);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->sc);
+  int rc = (e == hipSuccess) ? d->tr->allreduce(d->sc, dflag, 1, &terr) : GOGP_EHIP;
+  if (rc == GOGP_OK) {
+    e = hipMemcpyAsync(&hf, dflag, sizeof(double), hipMemcpyDeviceToHost, d->sc);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->sc);
+    if (e != hipSuccess) rc = GOGP_EHIP;
+  }
+  if (rc != GOGP_OK) {
+    h->err = std::string(what) + ": " + (terr.empty() ? "HIP error while agreeing on the status" : terr);
+    (void)hipGetLastError();
+    return rc;
+  }
+  if (hf != 0.0) {
+    if (!flag) h->err = std::string(what) + ": another rank failed before the collective";
+    return flag ? flag : GOGP_ESTATE;
+  }
+  return GOGP_OK;
+}
+
+// The whole factor on every rank, gathered in ROW BANDS of bounded size (<= 256 MiB of device scratch
+// per rank instead of one n x n buffer -- 34 GB at N = 65536, which would cancel the 1 / (Pr Pc) memory
+// footprint of the shards): per band every rank writes the rows its tiles hold into the zeroed band, one
+// all-reduce completes it, and it is copied to the host.
 template <class T>
 static int dist_get_factor_t(gogp_handle *h, double *Lout) {
   Dist2D *d = h->dist;
   const int nb = d->nb;
   const int64_t n = h->n;
   for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, d->sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  int64_t band = ((int64_t)(32 << 20) / n) / nb * nb;  // rows per band: 32 Mi doubles, whole tile rows
+  if (band < nb) band = nb;
   double *tmp = nullptr;
-  HIPCHK(h, hipMalloc(&tmp, (size_t)n * n * sizeof(double)));
-  hipError_t e = hipMemsetAsync(tmp, 0, (size_t)n * n * sizeof(double), d->sc);
-  for (int bj = 0; bj < d->nloc && e == hipSuccess; ++bj) {
-    const int gP = bj * d->Pc + d->pc;
-    for (int bi = 0; bi < d->mloc; ++bi) {
-      const int gI = bi * d->Pr + d->pr;
-      if (gI < gP || (int64_t)gI * nb >= n || (int64_t)gP * nb >= n) continue;
-      hipLaunchKernelGGL(scatter_tile_kernel<T>, dim3(nb), dim3(256), 0, d->sc,
-                         d->lchunk<T>(bj) + (size_t)bi * nb * nb, nb, tmp, (long)n, (long)gI * nb, (long)gP * nb,
-                         gI == gP ? 1 : 0);
-    }
+  const hipError_t ea = hipMalloc(&tmp, (size_t)band * n * sizeof(double));
+  if (ea != hipSuccess) (void)hipGetLastError();
+  int rc = agree_ok(h, d, ea == hipSuccess ? 0 : GOGP_ENOMEM, "sharded get_factor");
+  if (rc != GOGP_OK) {
+    (void)hipFree(tmp);
+    if (ea != hipSuccess) h->err = "sharded get_factor: out of device memory";
+    return rc;
   }
-  int rc = GOGP_OK;
+  hipError_t e = hipSuccess;
   std::string terr;
-  if (e == hipSuccess) rc = d->tr->allreduce(d->sc, tmp, n * n, &terr);
-  if (e == hipSuccess && rc == GOGP_OK)
-    e = hipMemcpyAsync(Lout, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, d->sc);
-  if (e == hipSuccess) e = hipStreamSynchronize(d->sc);
+  for (int64_t r0 = 0; r0 < n && e == hipSuccess && rc == GOGP_OK; r0 += band) {
+    const int64_t rows = std::min(band, n - r0);
+    e = hipMemsetAsync(tmp, 0, (size_t)rows * n * sizeof(double), d->sc);
+    for (int bi = 0; bi < d->mloc && e == hipSuccess; ++bi) {
+      const int64_t gI = (int64_t)bi * d->Pr + d->pr;
+      if (gI * nb < r0 || gI * nb >= r0 + rows) continue;  // bands hold whole tile rows
+      for (int bj = 0; bj < d->nloc; ++bj) {
+        const int64_t gP = (int64_t)bj * d->Pc + d->pc;
+        if (gI < gP || gP * nb >= n) continue;
+        // (the kernel's destination is the band: row index relative to r0)
+        hipLaunchKernelGGL(scatter_tile_kernel<T>, dim3(nb), dim3(256), 0, d->sc,
+                           d->lchunk<T>(bj) + (size_t)bi * nb * nb, nb, tmp - (size_t)r0 * n, (long)n, (long)gI * nb,
+                           (long)gP * nb, gI == gP ? 1 : 0);
+      }
+    }
+    if (e == hipSuccess) rc = d->tr->allreduce(d->sc, tmp, rows * n, &terr);
+    if (e == hipSuccess && rc == GOGP_OK)
+      e = hipMemcpyAsync(Lout + (size_t)r0 * n, tmp, (size_t)rows * n * sizeof(double), hipMemcpyDeviceToHost, d->sc);
+    if (e == hipSuccess && rc == GOGP_OK) e = hipStreamSynchronize(d->sc);  // the band buffer is reused
+  }
   (void)hipFree(tmp);
   if (rc != GOGP_OK) {
     h->err = "sharded get_factor: " + terr;
@@ -890,9 +949,24 @@ static int dist_get_factor_part_t(gogp_handle *h, const int64_t *rows, int64_t n
   const bool diag_only = rows == nullptr;
   const int64_t count = diag_only ? n : nrows * n, nblocks = diag_only ? n : nrows;
   for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, d->sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  int bad = 0;
+  for (int64_t k = 0; !diag_only && k < nrows; ++k)
+    if (rows[k] < 0 || rows[k] >= n) bad = GOGP_EARG;  // the kernel indexes the chunks with them
   double *tmp = nullptr;
   long *drows = nullptr;
-  HIPCHK(h, hipMalloc(&tmp, (size_t)count * sizeof(double)));
+  if (!bad && hipMalloc(&tmp, (size_t)count * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    bad = GOGP_ENOMEM;
+  }
+  {
+    const int rca = agree_ok(h, d, bad, "sharded get_factor_rows");
+    if (rca != GOGP_OK) {
+      (void)hipFree(tmp);
+      if (bad == GOGP_EARG) h->err = "get_factor_rows: row out of range";
+      if (bad == GOGP_ENOMEM) h->err = "sharded get_factor_rows: out of device memory";
+      return rca;
+    }
+  }
   hipError_t e = hipMemsetAsync(tmp, 0, (size_t)count * sizeof(double), d->sc);
   if (e == hipSuccess && !diag_only) {
     e = hipMalloc(&drows, (size_t)nrows * sizeof(long));
@@ -922,6 +996,113 @@ int gogp_dist_get_factor_part(gogp_handle *h, const int64_t *rows, int64_t nrows
   static_assert(sizeof(long) == sizeof(int64_t), "row indices are copied as they are");
   return h->prec == 32 ? dist_get_factor_part_t<float>(h, rows, nrows, out)
                        : dist_get_factor_part_t<double>(h, rows, nrows, out);
+}
+
+// ---- gogp_set_factor on a sharded handle: "Produce on stored results" (gp/gp.go:255-257) ------------
+// Collective; every rank passes the SAME dense n x n factor (what gogp_get_factor returns on every
+// rank) and alpha.  Each rank keeps its own tiles of L (cut out of the host matrix one local tile row
+// at a time through a staging buffer; rows / columns >= n get the identity padding of the padded
+// matrix), inverts every diagonal tile itself (the NB tile inverses are replicated state) and stores
+// alpha; no communication at all.  Y = L^-T is not rebuilt: Produce on the restored state runs the
+// distributed forward substitution with L and the tile inverses (dist_produce_t).
+template <class T>
+__global__ void scatter_stage_kernel(const double *__restrict__ stage, long lds_, T *__restrict__ Lch, int nloc,
+                                     int mloc, int bi, int nb) {
+  // stage: nb rows x (nloc * nb) columns (this rank's tile columns of one local tile row)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nb * nloc * nb;
+  if (i >= total) return;
+  const int r = (int)(i / ((long)nloc * nb));
+  const long cc = i - (long)r * nloc * nb;
+  const int bj = (int)(cc / nb), c = (int)(cc - (long)bj * nb);
+  Lch[((size_t)bj * mloc + bi) * nb * nb + (size_t)r * nb + c] = (T)stage[(long)r * lds_ + cc];
+}
+
+template <class T>
+static int dist_set_factor_t(gogp_handle *h, const double *Lin, const double *alpha) {
+  Dist2D *d = h->dist;
+  const int nb = d->nb, NB = d->NB, mloc = d->mloc, nloc = d->nloc, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc;
+  const int64_t n = h->n, npad = h->npad;
+  const size_t nb2 = (size_t)nb * nb;
+  hipStream_t s = h->s;
+  for (hipStream_t qs : {h->s, h->sp, h->st, h->s2, h->sl, d->sc}) HIPCHK(h, hipStreamSynchronize(qs));
+  int rc = gogp_upload_params(h);
+  if (rc != GOGP_OK) return rc;
+  // ---- my tiles of L ------------------------------------------------------------------------------
+  const size_t stage_elems = (size_t)nb * nloc * nb;
+  double *hst = nullptr, *dst = nullptr;
+  HIPCHK(h, hipHostMalloc((void **)&hst, stage_elems * sizeof(double), hipHostMallocDefault));
+  hipError_t e = hipMalloc(&dst, stage_elems * sizeof(double));
+  if (e != hipSuccess) {
+    (void)hipHostFree(hst);
+    HIPCHK(h, e);
+  }
+  for (int bi = 0; bi < mloc && e == hipSuccess; ++bi) {
+    const int64_t gI = (int64_t)bi * Pr + pr;
+    for (int r = 0; r < nb; ++r) {
+      const int64_t gi = gI * nb + r;
+      double *row = hst + (size_t)r * nloc * nb;
+      for (int bj = 0; bj < nloc; ++bj) {
+        const int64_t gc0 = ((int64_t)bj * Pc + pc) * nb;
+        double *dstp = row + (size_t)bj * nb;
+        for (int c = 0; c < nb; ++c) {
+          const int64_t gc = gc0 + c;
+          double v = 0.0;
+          if (gc <= gi) v = (gi < n) ? Lin[(size_t)gi * n + gc] : (gc == gi ? 1.0 : 0.0);
+          dstp[c] = v;
+        }
+      }
+    }
+    e = hipMemcpyAsync(dst, hst, stage_elems * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(scatter_stage_kernel<T>, dim3((unsigned)((stage_elems + 255) / 256)), dim3(256), 0, s, dst,
+                         (long)nloc * nb, d->mat<T>(d->Lch), nloc, mloc, bi, nb);
+      e = hipStreamSynchronize(s);  // the staging buffer is refilled by the next tile row
+    }
+  }
+  // ---- every diagonal tile's inverse, on every rank (fp64, rounded once on a float shard) -------------------
+  double *t64 = nullptr;  // [L tile | inverse] in fp64
+  if (e == hipSuccess) e = hipMalloc(&t64, 2 * nb2 * sizeof(double));
+  double logdet = 0.0;
+  for (int P = 0; P < NB && e == hipSuccess; ++P) {
+    for (int r = 0; r < nb; ++r) {
+      const int64_t gi = (int64_t)P * nb + r;
+      for (int c = 0; c < nb; ++c) {
+        const int64_t gc = (int64_t)P * nb + c;
+        hst[(size_t)r * nb + c] = (gc > gi) ? 0.0 : ((gi < n) ? Lin[(size_t)gi * n + gc] : (gc == gi ? 1.0 : 0.0));
+      }
+      if (gi < n) logdet += 2.0 * log(Lin[(size_t)gi * n + gi]);
+    }
+    e = hipMemcpyAsync(t64, hst, nb2 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) break;
+    double *Lt = t64, *Dv = t64 + nb2;
+    launch_diag256_inv_only_ld512(s, Lt, nb, Dv);
+    launch_diag256_inv_only_ld512(s, Lt + (size_t)PANEL * nb + PANEL, nb, Dv + (size_t)PANEL * nb + PANEL);
+    tile_inverse_offdiag(d, s, Lt + (size_t)PANEL * nb, Dv, nullptr);
+    launch_convert_block(s, Dv, nb, d->mat<T>(d->Dinv) + (size_t)P * nb2, nb, nb, nb);
+    e = hipStreamSynchronize(s);
+  }
+  (void)hipFree(t64);
+  (void)hipFree(dst);
+  (void)hipHostFree(hst);
+  HIPCHK(h, e);
+  // ---- alpha and the LML of the restored state: -n/2 log 2 pi - sum log L_ii - 1/2 y^T alpha ------------------
+  HIPCHK(h, hipMemsetAsync(h->alpha, 0, (size_t)npad * sizeof(double), s));
+  HIPCHK(h, hipMemcpyAsync(h->alpha, alpha, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_dot(s, h->dy, h->alpha, n, h->scalars);
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->scalars, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  h->lml = -0.5 * (double)n * log(2 * M_PI) - 0.5 * logdet - 0.5 * h->hscal[0];
+  h->factored = true;
+  h->have_alpha = true;
+  h->alpha_pending = false;
+  h->have_kinv = false;
+  h->trtri_done = false;  // no Y: Produce substitutes with L
+  return GOGP_OK;
+}
+int gogp_dist_set_factor(gogp_handle *h, const double *Lin, const double *alpha) {
+  return h->prec == 32 ? dist_set_factor_t<float>(h, Lin, alpha) : dist_set_factor_t<double>(h, Lin, alpha);
 }
 
 // ---- Produce on a sharded handle -----------------------------------------------------------------
@@ -1122,7 +1303,7 @@ static int produce_v_by_substitution(gogp_handle *h, Dist2D *d, const T *KsT, in
 template <class T>
 static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu, double *sigma) {
   Dist2D *d = h->dist;
-  if (!h->trtri_done) return fail(h, GOGP_ESTATE, "Produce: no factorisation");
+  if (!h->factored) return fail(h, GOGP_ESTATE, "Produce: no factorisation");
   const int nb = d->nb, Pr = d->Pr, Pc = d->Pc, pr = d->pr, pc = d->pc, mloc = d->mloc, nloc = d->nloc;
   const int64_t mpad = ((m + TILE - 1) / TILE) * TILE;
   const int64_t lrows = (int64_t)mloc * nb, lcols = (int64_t)nloc * nb;
@@ -1146,7 +1327,9 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
   PMALLOC(Xloc, lrows * h->D);
   PMALLOC(aloc, lrows);
   PMALLOC(Ks, mpad * lrows);
-  const bool by_substitution = sizeof(T) == 4;  // float shards: see produce_v_by_substitution
+  // float shards, and any shard whose factor was restored (gogp_set_factor: there is no Y = L^-T):
+  // see produce_v_by_substitution
+  const bool by_substitution = sizeof(T) == 4 || !h->trtri_done;
   if (!by_substitution) {
     PMALLOC(Yt, (int64_t)nb * lrows);
     PMALLOC(Vt, mpad * lcols);
@@ -1181,7 +1364,7 @@ static int dist_produce_t(gogp_handle *h, const double *Z, int64_t m, double *mu
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((mpad + 255) / 256)), dim3(256), 0, s, red2, 1.0 / Pc,
                        (long)mpad);
   const int mt = (int)(mpad / TILE);
-  if constexpr (sizeof(T) == 4) {
+  if (by_substitution) {
     const int rcs = produce_v_by_substitution<T>(h, d, Ks, lrows, mpad, m, red2 + mpad, qtmp, s, sc);
     if (rcs != GOGP_OK) {
       cleanup();

@@ -123,18 +123,30 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
         }
       }
       if (ARD_D > 0 && isard) {
+        // Everything that depends on the pass (ard0) sits in three base pointers; inside the unrolled
+        // loop q is a compile-time constant, i.e. an immediate offset of the LDS read, of the scalar
+        // loads and of the parameter load.  (With `d = ard0 + q` written out per q, hipcc hoisted 32
+        // LDS offsets, 32 `d < D` masks and 32 parameter addresses out of the tile loop and parked them
+        // in spill lanes: 190 SGPR spills in this instance.)
+        // No test of `ard0 + q < D` either (32 more hoisted masks): a slot beyond the last dimension
+        // multiplies by inv_len = 0 (fill_params zero-fills the table up to GOGP_MAX_NDIM), reads LDS past
+        // the column block (in range or, past the allocation, zero) and X past the row (the X buffer is
+        // allocated with GOGP_MAX_NDIM doubles of slack), and the host never looks at it.  The launcher
+        // picks the instance of each pass by the dimensions that are left, so at most half of a pass is
+        // such padding.
+        const double *cja = cj + ard0 * 64;
+        const double *xra = xr + ard0;
+        const double *ila = &P.inv_len[0][ard0];
 #pragma unroll
         for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {  // unrolled: ard[] stays in registers
-          const int d = ard0 + q;
-          if (d >= D) break;
-          const double il = P.inv_len[0][d];
-          const double c = cj[d * 64];
+          const double il = ila[q];
+          const double c = cja[q * 64];
           double a = ard[q];
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr)
             if (live & (1u << rr)) {
               const double g = gg[rr];
-              const double u = (xr[rr * D + d] - c) * il;
+              const double u = (xra[rr * D + q] - c) * il;
               a += g * u * u;
             }
           ard[q] = a;
@@ -238,11 +250,21 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
   else if (radial1 && ard_dims > 16) {
-    // the restructured instance is lean enough for 32 accumulators (189 VGPRs, no AGPRs, no scratch): half the
-    // passes, i.e. half the distance / exp work, for 17..64 ARD dimensions
-    for (int a0 = 0; a0 < ard_dims; a0 += 32)
-      hipLaunchKernelGGL((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
-                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+    // the restructured instance is lean enough for 32 accumulators (188 VGPRs, no AGPRs, no scratch): half the
+    // passes, i.e. half the distance / exp work, for 17..64 ARD dimensions; the last pass takes the
+    // smallest instance that holds what is left (the kernel does not test d < D per slot)
+    for (int a0 = 0; a0 < ard_dims; a0 += 32) {
+      const int left = ard_dims - a0;
+      if (left <= 8)
+        hipLaunchKernelGGL((grad_reduce_kernel<8, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+      else if (left <= 16)
+        hipLaunchKernelGGL((grad_reduce_kernel<16, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+      else
+        hipLaunchKernelGGL((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+    }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
 #undef GOGP_LAUNCH_GR
@@ -285,9 +307,18 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
   if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
   else if (radial1 && ard_dims > 16) {
-    for (int a0 = 0; a0 < ard_dims; a0 += 32)
-      hipLaunchKernelGGL((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
-                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+    for (int a0 = 0; a0 < ard_dims; a0 += 32) {
+      const int left = ard_dims - a0;
+      if (left <= 8)
+        hipLaunchKernelGGL((grad_reduce_kernel<8, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+      else if (left <= 16)
+        hipLaunchKernelGGL((grad_reduce_kernel<16, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+      else
+        hipLaunchKernelGGL((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+    }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL

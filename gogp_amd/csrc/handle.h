@@ -82,8 +82,11 @@ struct gogp_handle {
   int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
   int eager = 1;               // Observe also runs the triangular inverse (gradient
                                // preparation), interleaved with the Cholesky sweep
-  int kinv_fused = 1;          // ... and accumulates K^-1 = sum_P Y_P Y_P^T behind it, one rank-k update
-                               // per super-panel of Y (0: one LAUUM launch over the finished Y in Gradient)
+  int superpanel_head = 3;     // > 0: super-panel width while more than head_remaining panels are to come
+  int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
+  int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
+  int kinv_fused = -1;          // ... and accumulates K^-1 = sum_P Y_P Y_P^T behind it, one rank-k update
+                               // per super-panel of Y (0: one LAUUM launch over the finished Y in Gradient; -1: by size)
   int inv_prio = 0;            // 0: the inverse's streams at normal priority; 1: its bulk updates (s2) low;
                                // 2: bulk and chain (s2, st) low
   bool kinv_pending = false;   // K^-1 is being accumulated on sk (wait for EV_KINV)
@@ -188,3 +191,4 @@ int gogp_dist_produce(gogp_handle *h, const double *Z, int64_t m, double *mu, do
 int gogp_dist_get_factor(gogp_handle *h, double *Lout /* n*n, every rank */);
 // rows != nullptr: nrows selected rows of L (nrows x n); rows == nullptr: the diagonal (n); collective
 int gogp_dist_get_factor_part(gogp_handle *h, const int64_t *rows, int64_t nrows, double *out);
+int gogp_dist_set_factor(gogp_handle *h, const double *Lin /* n*n, every rank */, const double *alpha /* n */);

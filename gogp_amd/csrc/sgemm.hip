@@ -42,6 +42,7 @@ struct SGemmArgs {
   int trap;
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;  // GemmGrid, see dgemm.hip
   int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
+  int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
 };
 
 __device__ __forceinline__ void sload16_to_lds(const float *gsrc, float *lds_wave_base) {
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
   }
   if (MODE == GEMM_LOWER && ti >= g.new_row0) beta = 0.0f;
   int kbeg = 0, nkt = g.nkt;
+  if (MODE == GEMM_RECT && g.ktri) nkt = min(nkt, (tj + 1) * BT / SGEMM_BK);
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
     nkt = (g.kend - kbeg) / SGEMM_BK;
@@ -223,6 +225,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
   g.tpb_shift = g.rblk0 = g.cblk0 = g.pr = g.pc = g.beta0 = 0;
   g.Pr = g.Pc = 1;
   g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
+  g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
   if (grid && grid->rule) {
     g.rule = grid->rule;
     g.tpb_shift = grid->tpb_shift;
@@ -246,6 +249,11 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
   } else if (mode == GEMM_RECT) {
     ntiles = mt * nt;
     flops = 2.0 * (double)mt * TILE * (double)nt * TILE * (double)K;
+    if (g.ktri) {
+      flops = 0;
+      for (int j = 0; j < nt; ++j)
+        flops += 2.0 * (double)mt * TILE * TILE * (double)std::min<int64_t>(K, (int64_t)(j + 1) * TILE);
+    }
     if (g.rule) {
       const int tpb = 1 << g.tpb_shift;
       long kept = 0;

@@ -308,6 +308,31 @@ def gram_np(desc: CDesc, theta_s: np.ndarray, A: np.ndarray, B: np.ndarray,
     return (K, dK) if want_grad else K
 
 
+def potrf_blocked(K, nb=1024):
+    """Lower Cholesky factor of the C-ordered matrix K, in place (the strict upper triangle is left as it
+    was): right-looking blocked factorisation whose O(N^3) work is numpy matmul (threaded dgemm) on
+    panel-by-block products.  LAPACK's threaded dpotrf (OpenBLAS) collapses at some sizes on hosts with a
+    CPU quota far below the visible CPU count (GPU box, 16 of 256: N = 8192 ran at 32 GFLOP/s, as slow as
+    N = 16384); the CPU baseline of bench.py takes whichever of the two is faster.  gonum's own Dpotrf is
+    the same right-looking blocked algorithm (mat.Cholesky.Factorize, gp/gp.go:228)."""
+    import scipy.linalg as sla
+    n = K.shape[0]
+    for k in range(0, n, nb):
+        e = min(k + nb, n)
+        try:
+            L11 = sla.cholesky(K[k:e, k:e], lower=True, check_finite=False)
+        except np.linalg.LinAlgError as ex:
+            raise NotPositiveDefinite(-1) from ex
+        K[k:e, k:e] = L11
+        if e < n:
+            L21 = sla.solve_triangular(L11, K[e:, k:e].T, lower=True, check_finite=False).T
+            K[e:, k:e] = L21
+            for j in range(e, n, nb):
+                je = min(j + nb, n)
+                K[j:, j:je] -= L21[j - e:, :] @ L21[j - e:je - e, :].T
+    return K
+
+
 class FastOracle:
     """Restatement in the W-matrix form (hyperparameters-only Observe/Gradient,
     Absorb, Produce): LAPACK potrf/potri/potrs (scipy, OpenBLAS threads) for the
@@ -315,17 +340,26 @@ class FastOracle:
     default: gogp_oracle_gram_omp / gogp_oracle_grad_reduce_omp) or in numpy
     (``use_c=False``, kept as an independent cross-check)."""
 
-    def __init__(self, ndim: int, simil, noise=None, block: int = 1024, use_c: bool = True):
+    def __init__(self, ndim: int, simil, noise=None, block: int = 1024, use_c: bool = True,
+                 potrf: str = "lapack"):
         self.desc = build_desc(ndim, simil, noise)
         self.ndim = ndim
         self.ns = self.desc.ntheta_simil
         self.nn = 0 if self.desc.noise_kind == NOISE_CONSTANT else 1
         self.block = block
         self.use_c = use_c
+        #: "lapack" (scipy dpotrf) or "blocked" (potrf_blocked above: dgemm-based)
+        self.potrf = potrf
         self.X = np.zeros((0, ndim))
         self.Y = np.zeros((0,))
         self.Lc = None
         self.Alpha = None
+        #: seconds spent per phase since the last reset (bench.py's cpu_baseline reports them)
+        self.timings = {}
+
+    def _t(self, name, t0):
+        import time
+        self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
 
     def set_data(self, X, y):
         self.X = _arr(X).reshape(-1, self.ndim)
@@ -356,13 +390,23 @@ class FastOracle:
         if n == 0:
             self.Lc, self.Alpha = None, np.zeros(0)
             return
+        import time
+        t0 = time.perf_counter()
         K = self._gram(self.ts, self.tn)
-        try:
-            L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
-        except np.linalg.LinAlgError as e:
-            raise NotPositiveDefinite(-1) from e
+        self._t("gram", t0)
+        t0 = time.perf_counter()
+        if self.potrf == "blocked":
+            L = np.tril(potrf_blocked(K, self.block))
+        else:
+            try:
+                L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+            except np.linalg.LinAlgError as e:
+                raise NotPositiveDefinite(-1) from e
+        self._t("potrf", t0)
+        t0 = time.perf_counter()
         self.Lc = L
         self.Alpha = sla.cho_solve((L, True), self.Y, check_finite=False)
+        self._t("potrs", t0)
 
     def Absorb(self, X, y, theta_simil, theta_noise=()):
         self.set_data(X, y)
@@ -389,15 +433,24 @@ class FastOracle:
         g = np.zeros(P)
         if n == 0:
             return g
-        # K^-1 from the factor (dpotri); the lower triangle is valid
-        Kinv, info = sla.lapack.dpotri(self.Lc, lower=1, overwrite_c=0)
+        # K^-1 from the factor (dpotri).  LAPACK is column-major: handed the C-ordered factor as its
+        # transpose (a Fortran-ordered VIEW, the upper factor U = L^T) it inverts without the two
+        # 8 N^2-byte layout copies f2py would otherwise make; the result comes back as a Fortran-ordered
+        # array whose UPPER triangle is valid, i.e. -- read as C order -- the lower triangle of K^-1
+        import time
+        t0 = time.perf_counter()
+        Kinv_f, info = sla.lapack.dpotri(self.Lc.T, lower=0, overwrite_c=0)
         assert info == 0
+        Kinv = Kinv_f.T  # C-contiguous view, lower triangle valid
+        self._t("potri", t0)
         a = np.ascontiguousarray(self.Alpha)
         if self.use_c:
-            Kinv = np.ascontiguousarray(Kinv)
+            assert Kinv.flags.c_contiguous
             out = np.zeros(self.ns + 1)
+            t0 = time.perf_counter()
             lib().gogp_oracle_grad_reduce_omp(ctypes.byref(self.desc), _dp(self.ts), _dp(self.X),
                                               _dp(a), _dp(Kinv), n, _dp(out))
+            self._t("grad_reduce", t0)
             g[:self.ns] = out[:self.ns]
             trW = out[self.ns]
         else:

@@ -503,7 +503,8 @@ def test_config3_full_size_properties(gpmod):
 @pytest.mark.parametrize("shape", ["config4", "config5"])
 def test_config4_config5_shapes_full_size_properties(gpmod, shape):
     """The shapes of BASELINE configs 4 (Matern-5/2, reference coefficient, N=32768, D=16) and
-    5 (ARD-RBF, N=65536, D=32, P=34; in fp64 -- there is no fp32 path yet) on ONE GPU, through
+    5 (ARD-RBF, N=65536, D=32, P=34; here in fp64 -- as configured, in fp32, it runs in
+    test_config5_as_configured_fp32_full_size below) on ONE GPU, through
     the same size-independent properties as config 3: K alpha = y on sampled rows rebuilt on
     the host, gradient against a central difference of the LML along a random direction,
     and Produce at training inputs (mu_i = y_i - s2 alpha_i)."""
@@ -556,10 +557,60 @@ def test_config4_config5_shapes_full_size_properties(gpmod, shape):
     g.close()
 
 
+def test_config5_as_configured_fp32_full_size(gpmod):
+    """BASELINE configs[4] AS CONFIGURED: ARD-RBF, N = 65536, D = 32, precision = 32 (float matrices and
+    fp32 MFMA products, fp64 inputs / diagonal blocks / reductions / refinement of alpha; DESIGN.md
+    section 6), on one GPU.  Size-independent properties of the fp32 result itself -- K alpha = y on
+    sampled rows rebuilt on the host, the LML from the downloaded diagonal of the factor and y^T alpha,
+    Produce at training inputs -- and the fp64 path on the same data as the yardstick for LML, gradient
+    and alpha, within the bounds DESIGN.md section 6 states for this size."""
+    from gogp_amd import synth
+    N, D = 65536, 32
+    simil = kernel.Scaled(kernel.ARD(kernel.Normal, D))
+    ls = math.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D))  # SURVEY 8d
+    th = np.concatenate([[1.0], ls, [0.1]])
+    x = np.log(th)
+    s2 = th[-1] ** 2
+    X, y = synth.make_inputs(N, D, 20251114 + 4)
+    g32 = gpmod.GP(D, simil, kernel.UniformNoise, X=X, Y=y, precision=32)
+    lml32 = g32.Observe(x)
+    grad32 = g32.Gradient()
+    a32 = g32.Alpha
+    assert np.isfinite(lml32) and np.isfinite(grad32).all() and grad32.shape == x.shape
+    rng = np.random.default_rng(5)
+    # K alpha = y with the exact (fp64, host) rows of K: alpha was refined against the exact Gram matrix
+    for i in rng.integers(0, N, 8):
+        krow = th[0] * np.exp(-0.5 * (((X[i] - X) / ls) ** 2).sum(1))
+        krow[i] += s2
+        assert abs(krow @ a32 - y[i]) <= 2e-5 * max(1.0, np.abs(krow * a32).sum()), i
+    # the LML from its parts: log-determinant from the downloaded (float) diagonal, quadratic term y^T alpha
+    d = g32.L_diag()
+    assert d.shape == (N,) and np.all(d > 0)
+    lml_parts = -0.5 * N * math.log(2 * math.pi) - np.log(d).sum() - 0.5 * float(y @ a32)
+    assert abs(lml_parts - lml32) <= 2e-6 * abs(lml32), (lml_parts, lml32)
+    idx = rng.integers(0, N, 512)
+    mu, sigma = g32.Produce(X[idx])
+    np.testing.assert_allclose(mu, (y - s2 * a32)[idx], rtol=0, atol=2e-3 * max(1.0, np.abs(y).max()))
+    assert np.all(np.isfinite(sigma)) and np.all(sigma < th[-1] * 1.01)
+    # the fp64 path on the same data (96 GB next to the 48 GB of the fp32 handle: both fit one MI355X)
+    g64 = gpmod.GP(D, simil, kernel.UniformNoise, X=X, Y=y)
+    lml64 = g64.Observe(x)
+    grad64 = g64.Gradient()
+    a64 = g64.Alpha
+    assert abs(lml32 - lml64) <= 2e-6 * abs(lml64), (lml32, lml64)                      # measured 7.5e-7
+    assert np.abs(grad32 - grad64).max() <= 5e-4 * np.abs(grad64).max(), (grad32, grad64)  # measured 1.2e-4
+    assert np.abs(a32 - a64).max() <= 1e-4 * np.abs(a64).max()                          # measured 2.2e-5
+    g32.close()
+    g64.close()
+
+
 @pytest.mark.parametrize("opts", [
     {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}, {"superpanel": 4}, {"superpanel": 8},
     {"superpanel": 6, "eager": 0},
     {"lookahead": 0, "superpanel": 4},
+    {"kinv_fused": 0}, {"kinv_fused": 1}, {"kinv_fused": 1, "superpanel": 3}, {"ktri": 0},
+    {"superpanel_head": 3, "head_remaining": 2}, {"superpanel_head": 4, "head_remaining": 0},
+    {"superpanel_head": 3, "head_remaining": 4, "kinv_fused": 1}, {"superpanel_head": 5, "head_remaining": 3, "eager": 0},
 ], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("n", [300, 2300])
 def test_schedule_options_same_results(gpmod, opts, n):

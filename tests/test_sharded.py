@@ -89,6 +89,17 @@ def test_sharded_grid_matches_single_gpu(grid):
                 rows = np.array([0, n // 3, 513 % n, n - 1])  # selected rows and the diagonal: collective too
                 np.testing.assert_array_equal(sh.L_rows(rows), Lf[rows])
                 np.testing.assert_array_equal(sh.L_diag(), np.diag(Lf))
+                # "Produce on stored results" (gp/gp.go:255-257) on the shards: every rank re-installs its
+                # tiles of the gathered factor; Produce then substitutes with L (there is no Y = L^-T)
+                al = sh.Alpha
+                sh.restore(Lf, al)
+                assert abs(sh.LML() - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+                mu, sg = sh.Produce(ref["Z"])
+                np.testing.assert_allclose(mu, ref["mu"], rtol=1e-8, atol=1e-10)
+                np.testing.assert_allclose(sg, ref["sigma"], rtol=1e-7, atol=1e-10)
+                np.testing.assert_array_equal(sh.L, Lf)  # the tiles came back unchanged
+                with pytest.raises(Exception):
+                    sh.Gradient()  # restored state has no gradient (gp/gp.go:85-86)
             nbytes = sh.local_bytes()
             sh.close()
             return nbytes
@@ -104,6 +115,48 @@ def test_sharded_grid_matches_single_gpu(grid):
                    + npad * (D + 3) + mloc + 2 * npad + 1 + world)
         for b in outs:
             assert n2 <= b <= n2 + lin + (1 << 22), (b, n2, lin)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("grid", [(1, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
+def test_lbfgs_over_sharded_handle(grid, precision):
+    """BASELINE configs[4]: "LML+grad inside L-BFGS hyperparameter loop" on the shards
+    (tutorial/tutorial.go:128-155 on one process).  optimize.lbfgs drives a ShardedGP on every rank:
+    LML and gradient are all-reduced, so every rank runs the identical iteration -- the same iterates
+    bit for bit on all ranks -- and the run follows the single-GPU optimisation from the same start."""
+    from gogp_amd import gp as G
+    from gogp_amd import kernel, optimize, synth
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    world = grid[0] * grid[1]
+    n, D = 1500, 3
+    simil = kernel.Scaled(kernel.ARD(kernel.Normal, D))
+    X, y = synth.make_inputs(n, D, 77)
+    x0 = np.log(np.concatenate([[0.8], np.full(D, 0.9), [0.3]]))
+    iters = 6
+    one = G.GP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0, precision=precision)
+    want = optimize.lbfgs(one, x0, major_iterations=iters, gradient_threshold=1e-12)
+    one.close()
+    assert want.lml > want.history[0] + 1.0  # the optimiser moved
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                       exchange=lb.exchange, allreduce=lb.allreduce, precision=precision)
+        res = optimize.lbfgs(sh, x0, major_iterations=iters, gradient_threshold=1e-12)
+        sh.close()
+        return res
+
+    outs, _ = loopback.run_ranks(world, rank_fn)
+    for res in outs[1:]:  # every rank ran the same iteration
+        np.testing.assert_array_equal(res.x, outs[0].x)
+        assert res.history == outs[0].history and res.evaluations == outs[0].evaluations
+    tol = 1e-7 if precision == 64 else 2e-3
+    got = outs[0]
+    assert got.iterations == want.iterations
+    assert abs(got.lml - want.lml) <= tol * abs(want.lml), (got.lml, want.lml)
+    np.testing.assert_allclose(got.x, want.x, rtol=0, atol=1e3 * tol)
+    np.testing.assert_allclose(got.history[:3], want.history[:3], rtol=max(tol, 1e-9))
 
 
 def expected_exchange_bytes(npad, grid, nb=512):
@@ -384,6 +437,14 @@ for (n, D, simil) in [(700, 3, kernel.Scaled(kernel.Normal)), (2300, 2, kernel.S
     mu_r, sg_r = ref.Produce(Z)
     np.testing.assert_allclose(mu, mu_r, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(sg, sg_r, rtol=1e-7, atol=1e-10)
+    # the optimiser over the sharded handle: all-reduced LML / gradient keep the ranks in step
+    from gogp_amd import optimize
+    res = optimize.lbfgs(sh, x, major_iterations=3, gradient_threshold=1e-12)
+    res_1 = optimize.lbfgs(ref, x, major_iterations=3, gradient_threshold=1e-12)
+    assert abs(res.lml - res_1.lml) <= 1e-7 * abs(res_1.lml), (rank, res.lml, res_1.lml)
+    t = torch.tensor(res.x.copy())
+    dist.broadcast(t, src=0)
+    assert np.array_equal(t.numpy(), res.x), (rank, "iterates differ between ranks")
     sh.close()
     ref.close()
 dist.barrier()
