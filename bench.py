@@ -91,8 +91,8 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
     x = wl.log_theta(0)
     Z = wl.test_points(1024 if N >= 1024 else 16)
 
-    def run(n, potrf="lapack", gradient=True):
-        o = FastOracle(D, wl.simil, wl.noise, block=1024, potrf=potrf)
+    def run(n, potrf="lapack", gradient=True, potri="lapack"):
+        o = FastOracle(D, wl.simil, wl.noise, block=1024, potrf=potrf, potri=potri)
         o.set_data(X[:n], y[:n])
         t0 = time.time()
         lml = o.Observe(x)
@@ -107,22 +107,36 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
         rep = {"n": n, "seconds_lapack_potrf": dt, "phases_s": ph}
         secs = dt
         if n >= 2048:
-            ob, lml_b, _, _ = run(n, potrf="blocked", gradient=False)
+            # the dgemm-based twins of the two O(N^3) LAPACK calls; per phase the faster one counts.  (The
+            # blocked inverse does 1.5x the flops of dpotri: at N = 16384, where dpotri runs at 660 GFLOP/s
+            # on the GPU box's 16 cores, it is only tried when dpotri is slower than 300 GFLOP/s.)
+            slow_potri = 2 * float(n) ** 3 / 3 / max(o.timings["potri"], 1e-9) < 300e9
+            ob, lml_b, g_b, _ = run(n, potrf="blocked", gradient=slow_potri, potri="blocked")
             pb = ob.timings["potrf"]
             rep["potrf_blocked_s"] = round(pb, 4)
             rep["lml_rel_diff_blocked_vs_lapack"] = abs(lml_b - lml) / abs(lml)
-            del ob
             if pb < o.timings["potrf"]:
-                secs = dt - o.timings["potrf"] + pb
+                secs -= o.timings["potrf"] - pb
                 rep["factorisation_counted"] = "blocked (dgemm-based)"
             else:
                 rep["factorisation_counted"] = "LAPACK dpotrf"
+            rep["inverse_counted"] = "LAPACK dpotri"
+            if slow_potri:
+                qb = ob.timings["potri"]
+                rep["potri_blocked_s"] = round(qb, 4)
+                rep["grad_rel_diff_blocked_vs_lapack"] = float(np.abs(g_b - g).max() / max(1.0, np.abs(g).max()))
+                if qb < o.timings["potri"]:
+                    secs -= o.timings["potri"] - qb
+                    rep["inverse_counted"] = "blocked (dgemm-based)"
+            del ob
         rep["seconds"] = secs
         flop = float(n) ** 3
         rep["gflops"] = {"potrf_lapack": round(flop / 3 / max(o.timings["potrf"], 1e-9) / 1e9, 1),
                          "potri": round(2 * flop / 3 / max(o.timings["potri"], 1e-9) / 1e9, 1)}
         if "potrf_blocked_s" in rep:
             rep["gflops"]["potrf_blocked"] = round(flop / 3 / max(rep["potrf_blocked_s"], 1e-9) / 1e9, 1)
+        if "potri_blocked_s" in rep:  # useful flop of the inverse (the blocked twin executes 1.5x as many)
+            rep["gflops"]["potri_blocked"] = round(2 * flop / 3 / max(rep["potri_blocked_s"], 1e-9) / 1e9, 1)
         return o, lml, g, secs, rep
 
     # untimed warm-up: thread pools, first-touch page-in of OpenBLAS / libgomp
@@ -162,8 +176,11 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
         out["second_sample"] = {"n": second_sample_n, "seconds": dt2, "detail": rep2,
                                 "evals_per_s_scaled_to_N": (1.0 / dt2) * (second_sample_n / float(N)) ** 3,
                                 "time_ratio_over_n3_law": ratio,
-                                "note": "time(N) / time(n) divided by (N/n)^3: 1 = the N^3 law; the O(N^3) "
-                                        "LAPACK calls run at a higher rate at the larger size (see gflops)"}
+                                "note": "time(N) / time(n) divided by (N/n)^3: 1 = the N^3 law.  OpenBLAS's threaded "
+                                        "dpotrf / dpotri collapse at N = 8192 on the GPU boxes (16-CPU quota on a "
+                                        "256-CPU host: 32 and 75 GFLOP/s against 247 and 663 at N = 16384), so per "
+                                        "phase the faster of LAPACK and a dgemm-based blocked twin counts; what is "
+                                        "left of the gap is the rate of dgemm itself at the two sizes (gflops)"}
     # the reference's own algorithm (dense dK per parameter, r0 = aa^T dK, r1 = K^-1 dK:
     # gp/gp.go:476-485; 4P N^3 flop) as restated by the faithful C oracle, single thread,
     # at a size it finishes in about a second, extrapolated by its N^3 law
@@ -182,16 +199,23 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
     return out, errs
 
 
-def pmc_traffic(config):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary of the same
-    command (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py from separate
-    rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 correction); None if absent."""
+def pmc_traffic(config, build_id):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of the same command
+    (profiles/r03_pmc_traffic.json, written by tools/pmc_traffic.py from separate rocprofv3 --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction).  The file is stamped with the build id of the library
+    it was measured on (gogp_version(): hash of the library's sources); with another build the number is
+    stale and is NOT reported.  Returns (entry or None, reason)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             d = json.load(f)
-        return d.get(str(config))
     except Exception:
-        return None
+        return None, "no profiles/r03_pmc_traffic.json"
+    e = d.get(str(config))
+    if e is None:
+        return None, "no PMC pass for this configuration"
+    if d.get("build") != build_id:
+        return None, "stale: measured on build %s, this library is build %s" % (d.get("build"), build_id)
+    return e, None
 
 
 def launch_ranks(ngpus, argv):
@@ -551,10 +575,15 @@ def main():
                         "on this device",
             },
         }
-        tr = pmc_traffic(wl.config)
+        version = G._lib.lib().gogp_version().decode()
+        build_id = version.split("build ")[-1] if "build " in version else "unknown"
+        out["library"] = version
+        tr, why = pmc_traffic(wl.config, build_id)
         if tr is not None and tr.get("N") == N and not sharded_value:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_note"] = tr.get("note")
+        else:
+            out["roofline"]["traffic_note"] = "not reported: " + (why or "measured at another size / on one GPU only")
         if gram_n and grad_n:
             w = 512  # the first super-panel's block columns are built on the panel stream
             gram_bytes = 8.0 * max(0, N - w) ** 2 / 2.0 * cps

@@ -66,7 +66,10 @@ extern "C" int gogp_desc_check(const gogp_desc *d) {
 }
 
 extern "C" const char *gogp_version(void) {
-  return "gogp_hip 0.1 gfx950 fp64-mfma(v_mfma_f64_16x16x4_f64) tile128 panel256";
+#ifndef GOGP_BUILD_ID
+#define GOGP_BUILD_ID "unknown"
+#endif
+  return "gogp_hip 0.3 gfx950 fp64-mfma(v_mfma_f64_16x16x4_f64) tile128 panel256 build " GOGP_BUILD_ID;
 }
 
 extern "C" const char *gogp_last_error(const gogp_handle *h) {

@@ -333,6 +333,37 @@ def potrf_blocked(K, nb=1024):
     return K
 
 
+def _tri_inv(L, nb):
+    """Inverse of a lower triangular matrix by recursive halving: [[A, 0], [B, C]]^-1 =
+    [[A^-1, 0], [-C^-1 B A^-1, C^-1]]; the products are plain (threaded) matmuls."""
+    import scipy.linalg as sla
+    n = L.shape[0]
+    if n <= nb:
+        Y, info = sla.lapack.dtrtri(np.asfortranarray(L), lower=1)
+        assert info == 0
+        return np.tril(Y)
+    h = (n // 2 + nb - 1) // nb * nb
+    Y = np.zeros((n, n))
+    Y[:h, :h] = _tri_inv(L[:h, :h], nb)
+    Y[h:, h:] = _tri_inv(L[h:, h:], nb)
+    Y[h:, :h] = -(Y[h:, h:] @ (L[h:, :h] @ Y[:h, :h]))
+    return Y
+
+
+def potri_blocked(L, nb=1024):
+    """K^-1 (lower triangle valid) from the lower Cholesky factor: Y = L^-1 by recursive halving, then
+    K^-1 = Y^T Y block column by block column -- every O(N^3) product a threaded matmul (counterpart of
+    potrf_blocked above; the reference forms K^-1 dK_p by SolveTo per parameter, gp/gp.go:480)."""
+    n = L.shape[0]
+    Y = _tri_inv(L, nb)
+    Kinv = np.zeros((n, n))
+    for i in range(0, n, nb):
+        e = min(i + nb, n)
+        # rows i:e of K^-1, columns 0:e = sum over k >= i of Y[k, i:e]^T Y[k, 0:e]
+        Kinv[i:e, :e] = Y[i:, i:e].T @ Y[i:, :e]
+    return Kinv
+
+
 class FastOracle:
     """Restatement in the W-matrix form (hyperparameters-only Observe/Gradient,
     Absorb, Produce): LAPACK potrf/potri/potrs (scipy, OpenBLAS threads) for the
@@ -341,7 +372,7 @@ class FastOracle:
     (``use_c=False``, kept as an independent cross-check)."""
 
     def __init__(self, ndim: int, simil, noise=None, block: int = 1024, use_c: bool = True,
-                 potrf: str = "lapack"):
+                 potrf: str = "lapack", potri: str = "lapack"):
         self.desc = build_desc(ndim, simil, noise)
         self.ndim = ndim
         self.ns = self.desc.ntheta_simil
@@ -350,6 +381,7 @@ class FastOracle:
         self.use_c = use_c
         #: "lapack" (scipy dpotrf) or "blocked" (potrf_blocked above: dgemm-based)
         self.potrf = potrf
+        self.potri = potri
         self.X = np.zeros((0, ndim))
         self.Y = np.zeros((0,))
         self.Lc = None
@@ -439,9 +471,12 @@ class FastOracle:
         # array whose UPPER triangle is valid, i.e. -- read as C order -- the lower triangle of K^-1
         import time
         t0 = time.perf_counter()
-        Kinv_f, info = sla.lapack.dpotri(self.Lc.T, lower=0, overwrite_c=0)
-        assert info == 0
-        Kinv = Kinv_f.T  # C-contiguous view, lower triangle valid
+        if self.potri == "blocked":
+            Kinv = potri_blocked(self.Lc, self.block)
+        else:
+            Kinv_f, info = sla.lapack.dpotri(self.Lc.T, lower=0, overwrite_c=0)
+            assert info == 0
+            Kinv = Kinv_f.T  # C-contiguous view, lower triangle valid
         self._t("potri", t0)
         a = np.ascontiguousarray(self.Alpha)
         if self.use_c:

@@ -1,7 +1,9 @@
 """HBM-side bytes per launch of the dominant kernel family from the separate rocprofv3 --pmc passes
 (FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of
 a wide coalesced read, so it is doubled -- MI355X_MICROARCH.md, section HBM).
-usage: pmc_traffic.py <config> <fetch_dir> <write_dir> <family-substring>  -> one JSON object on stdout"""
+usage: pmc_traffic.py <config> <fetch_dir> <write_dir> <family-substring> [N]  -> one JSON object on stdout
+(tools/profile_round3.sh merges the objects of several configurations and stamps the file with the
+library's build id)"""
 import collections, csv, glob, json, sys
 cfg, fdir, wdir, fam = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 def load(path, counter):
@@ -15,7 +17,9 @@ def load(path, counter):
 fetch, nf = load(fdir, 'FETCH_SIZE')
 write, nw = load(wdir, 'WRITE_SIZE')
 bytes_total = (2.0 * fetch + write) * 1024.0
+Nobs = int(sys.argv[5]) if len(sys.argv) > 5 else None
 print(json.dumps({cfg: {
+    "N": Nobs,
     "bytes_per_launch": bytes_total / max(1, nf),
     "launches_counted": nf,
     "fetch_bytes_corrected": 2.0 * fetch * 1024.0, "write_bytes": write * 1024.0,
