@@ -1,12 +1,15 @@
 """Rank plumbing for multi-GPU runs (one process per GPU, torch.distributed;
 backend "nccl" is RCCL on ROCm, "gloo" for CPU rehearsals).
 
-Round-1 sharding of the path across GPUs: the hyperparameter optimiser's
-independent candidates (multi-start points, line-search trial points) are dealt
-round-robin to the ranks; every rank holds the full X, y and evaluates its own
-candidates with no data-path collective.  Results are gathered with one
-all_gather of (LML, gradient) per batch.  The 2-D block-cyclic factorisation of
-ONE evaluation over several GPUs is the next row.
+Two things shard:
+  * independent evaluations -- the hyperparameter optimiser's candidates (multi-start points,
+    line-search trial points) dealt round-robin to the ranks, every rank holding the full X, y and
+    evaluating its own candidates with no data-path collective; results meet in one all_gather of
+    (LML, gradient) per batch.  That is what this module serves (my_candidates, gather_results) and what
+    bench.py reports as `value` for BASELINE configs 1-3 on N > 1 GPUs;
+  * ONE evaluation over all GPUs: the 2-D block-cyclic factorisation with RCCL inside the library
+    (gogp_amd/sharded.py: ShardedGP; gogp_amd/csrc/dist2d.hip) -- BASELINE configs 4 and 5.
+The reference has no counterpart (single process, goroutines only: gp/gp.go:165-213).
 """
 from __future__ import annotations
 

@@ -45,4 +45,16 @@ for a, b, f, tg in zip(t0, t1, fl, tag):
 print("class (mode, K, size): launches, GFLOP, summed duration ms, GFLOP / summed ms")
 for k, c in sorted(cls.items(), key=lambda kv: -kv[1][1]):
     print("  %-22s %4d  %9.1f  %8.2f  %6.1f" % (k, c[0], c[1] / 1e9, c[2], c[1] / 1e9 / max(c[2], 1e-9)))
+# idle time of the two bulk streams: the Cholesky trailing updates (mode 1, K >= 512, not small) run in order on
+# the main stream, the inverse's big updates (mode 0, K >= 512, not small) on s2 -- the gap between one such
+# launch's end and the next one's start is time that stream waited for the chain
+for name, sel in (("Cholesky bulk (LOWER)", lambda m, K, t: m == 1 and K >= 512 and t >= 384),
+                  ("inverse bulk (RECT big/mid)", lambda m, K, t: m == 0 and K >= 512 and t >= 384)):
+    iv = sorted((a, b) for a, b, tg in zip(t0, t1, tag)
+                if sel(tg // 100000000, (tg // 100000) % 1000 * 16, tg % 100000))
+    gaps = [(iv[i + 1][0] - iv[i][1], iv[i][1]) for i in range(len(iv) - 1)]
+    pos = [g for g in gaps if g[0] > 0]
+    print("%s: %d launches, busy %.2f ms, idle between them %.2f ms in %d gaps; largest: %s" % (
+        name, len(iv), sum(b - a for a, b in iv), sum(g for g, _ in pos), len(pos),
+        ", ".join("%.2f ms at t=%.1f" % g for g in sorted(pos, reverse=True)[:6])))
 g.close()
