@@ -221,6 +221,19 @@ void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int a
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
                               double *out, bool radial1 = false);
 
+// grad_mfma.hip: the reduction pass for ONE radial term with ARD length scales, distances and per-dimension sums
+// on the matrix cores; ntc == 0: lower triangle of an unsharded K^-1 (nt x nt tiles of 64, candidate batching
+// honoured), ntc > 0: the local nt x ntc tiles of a 2-D block-cyclic one.  Writes `blocks` x NACC partials.
+void launch_grad_ard_mfma(hipStream_t s, const DevParams *p, int ndim, const double *X, const double *alpha,
+                          const double *Kinv, int64_t ld, int64_t n, int nt, int ntc, int ntiles, int blocks,
+                          BlockMap map, double *partials);
+void launch_grad_ard_mfma(hipStream_t s, const DevParams *p, int ndim, const double *X, const double *alpha,
+                          const float *Kinv, int64_t ld, int64_t n, int nt, int ntc, int ntiles, int blocks,
+                          BlockMap map, double *partials);
+// ARD kernels with at least this many dimensions take it (below, the per-dimension work is small and the
+// scalar-row kernel of grad.hip is as fast)
+constexpr int ARD_MFMA_MIN_DIMS = 12;
+
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}
 void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,

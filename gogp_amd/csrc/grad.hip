@@ -247,7 +247,10 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
                          alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
                          tl_batch.stride);                                                        \
   } while (0)
-  if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
+  if (radial1 && ard_dims >= ARD_MFMA_MIN_DIMS)
+    // one radial term, many ARD length scales: distances and per-dimension sums on the matrix cores
+    launch_grad_ard_mfma(s, p, ndim, X, alpha, Kinv, ld, n, nt, 0, ntiles, blocks, BlockMap(), partials);
+  else if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GR(8, 0);
   else if (radial1 && ard_dims > 16) {
     // the restructured instance is lean enough for 32 accumulators (188 VGPRs, no AGPRs, no scratch): half the
@@ -304,7 +307,9 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
       hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                          Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
   } while (0)
-  if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
+  if (radial1 && ard_dims >= ARD_MFMA_MIN_DIMS)
+    launch_grad_ard_mfma(s, p, ndim, X, alpha, Kinv, ld, n, nt, ntc, ntiles, blocks, map, partials);
+  else if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
   else if (radial1 && ard_dims > 16) {
     for (int a0 = 0; a0 < ard_dims; a0 += 32) {

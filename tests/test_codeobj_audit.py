@@ -7,7 +7,8 @@ metadata of every kernel in libgogp_hip.so (tools/codeobj_audit.py: .hip_fatbin 
 -> `llvm-readelf --notes`) and pins:
 
   * no VGPR spills anywhere (vgpr_spill_count == 0): neither scratch nor AGPR spill copies;
-  * no AGPRs at all outside MFMA kernels (the tile kernels use none either: accumulators are VGPRs);
+  * no AGPRs except as MFMA accumulators of an allow-listed kernel (the tile kernels use none: their
+    accumulators are VGPRs);
   * at most 256 VGPRs per kernel (so that two waves fit on a SIMD);
   * no private (scratch) segment;
   * SGPR spills (lanes of a reserved VGPR -- slow on a critical path, not wrong) bounded, with an explicit
@@ -65,10 +66,21 @@ def test_every_hot_kernel_is_present(kernels):
         assert want in names, want
 
 
+#: kernels that may use AGPRs: MFMA accumulators the compiler keeps there (written by MFMA under the full
+#: EXEC mask and recomputed per tile -- never a parking place for values that live across divergent
+#: trips, which is what the removed instances' spill copies were)
+AGPR_ALLOW = {r"grad_ard_mfma_kernel<\d+, (true|false), (double|float)>": 64}
+
+
 def test_no_vgpr_spills_no_scratch_no_agprs(kernels):
+    def agprs_ok(k):
+        for pat, allowed in AGPR_ALLOW.items():
+            if re.search(pat, k["name"]) and k.get("agpr_count", 0) <= allowed:
+                return True
+        return k.get("agpr_count", 0) == 0
     bad = [(k["name"], k.get("vgpr_spill_count", 0), k.get("private_segment_fixed_size", 0), k.get("agpr_count", 0))
            for k in kernels
-           if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0) or k.get("agpr_count", 0)]
+           if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0) or not agprs_ok(k)]
     assert not bad, "kernels with VGPR spills / scratch / AGPRs (name, vgpr spills, scratch bytes, agprs): %r" % bad
 
 

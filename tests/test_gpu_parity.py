@@ -282,16 +282,20 @@ def test_ard_gradient_many_dimensions_two_terms(gpmod, D, n):
     g.close()
 
 
-@pytest.mark.parametrize("D,n", [(17, 900), (24, 900), (32, 900), (33, 900), (40, 4200), (64, 4200)])
-def test_ard_gradient_many_dimensions(gpmod, D, n):
-    """ARD kernels with more than 16 length scales: the fused gradient reduction keeps 16 (32 in the
-    single-radial-term instances) per-dimension accumulators in registers and takes one pass per
-    16 (32) dimensions; n = 4200 gives every workgroup several tiles.  Against the oracle, and
-    bit-for-bit repeatable."""
+@pytest.mark.parametrize("kind", ["normal", "matern52"])
+@pytest.mark.parametrize("D,n", [(9, 900), (12, 900), (16, 2300), (17, 900), (24, 900), (32, 900), (33, 900), (40, 4200),
+                                 (48, 700), (49, 1300), (64, 4200)])
+def test_ard_gradient_many_dimensions(gpmod, D, n, kind):
+    """ARD kernels with one radial term and 12 or more length scales take grad_mfma.hip: distances and the
+    per-dimension sums on the matrix cores (S = Xs Xs^T and P = G Xs per 64x64 tile), every D padded to a
+    multiple of 16; below 12 dimensions the scalar-row kernel of grad.hip.  n = 4200 gives every workgroup
+    several tiles, D = 16 / 32 / 48 / 64 are the exact pad sizes, 17 / 33 / 49 one past them.  Against the
+    oracle, and bit-for-bit repeatable."""
     from oracle.oracle import FastOracle
     rng = np.random.default_rng(100 + D)
     X, y = _data(rng, n, D)
-    simil, noise = kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise
+    base = kernel.Normal if kind == "normal" else kernel.Matern52
+    simil, noise = kernel.Scaled(kernel.ARD(base, D)), kernel.UniformNoise
     th = np.concatenate([[1.1], np.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D)), [0.2]])
     x = np.log(th)
     g = gpmod.GP(D, simil, noise, X=X, Y=y)
