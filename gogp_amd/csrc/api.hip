@@ -1029,10 +1029,10 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
       AuxTimer tm(h, GOGP_PROF_GRAD, s);
       if (h->prec == 32)
         launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha,
-                           reinterpret_cast<const float *>(h->bufA), h->npad, h->n, h->npad, h->gpart, h->gout, h->radial1);
+                           reinterpret_cast<const float *>(h->bufA), h->npad, h->n, h->npad, h->gpart, h->gout, h->radial1, h->ard_mfma_min);
       else
         launch_grad_reduce(s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n,
-                           h->npad, h->gpart, h->gout, h->radial1);
+                           h->npad, h->gpart, h->gout, h->radial1, h->ard_mfma_min);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1248,7 +1248,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     {
       AuxTimer tm(h, GOGP_PROF_GRAD, h->s);
       launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n, h->npad,
-                         h->gpart, h->gout, h->radial1);
+                         h->gpart, h->gout, h->radial1, h->ard_mfma_min);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
     // every stream joins the main one (the end of a captured graph; harmless otherwise)
@@ -1763,6 +1763,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "head_remaining") == 0) {
     if (value < 0) return fail(h, GOGP_EARG, "head_remaining must be >= 0");
     h->head_remaining = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "ard_mfma_min_dims") == 0) {
+    if (value < 1 || value > 65) return fail(h, GOGP_EARG, "ard_mfma_min_dims must be 1..65");
+    h->ard_mfma_min = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "ktri") == 0) {

@@ -146,7 +146,7 @@ void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float 
                           int cols);
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims, const double *X,
                         const double *alpha, const float *Kinv, int64_t ld, int64_t n, int64_t npad,
-                        double *partials, double *out, bool radial1 = false);
+                        double *partials, double *out, bool radial1 = false, int mfma_min_dims = 1);
 
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
                        int64_t n, int64_t npad, double *K, int64_t ld);
@@ -208,18 +208,18 @@ int grad_reduce_blocks(int64_t npad);
 // fused gradient reduction over lower tiles of Kinv; out: NACC doubles
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
-                        int64_t npad, double *partials, double *out, bool radial1 = false);
+                        int64_t npad, double *partials, double *out, bool radial1 = false, int mfma_min_dims = 1);
 // the same over the LOCAL tiles (mrows x ncols, leading dimension ld) of a 2-D block-cyclic
 // K^-1: tiles of the global lower triangle only; `partials` needs grad_reduce_blocks_local
 int grad_reduce_blocks_local(int64_t mrows, int64_t ncols);
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out, bool radial1 = false);
+                              double *out, bool radial1 = false, int mfma_min_dims = 1);
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const float *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out, bool radial1 = false);
+                              double *out, bool radial1 = false, int mfma_min_dims = 1);
 
 // grad_mfma.hip: the reduction pass for ONE radial term with ARD length scales, distances and per-dimension sums
 // on the matrix cores; ntc == 0: lower triangle of an unsharded K^-1 (nt x nt tiles of 64, candidate batching
@@ -230,9 +230,9 @@ void launch_grad_ard_mfma(hipStream_t s, const DevParams *p, int ndim, const dou
 void launch_grad_ard_mfma(hipStream_t s, const DevParams *p, int ndim, const double *X, const double *alpha,
                           const float *Kinv, int64_t ld, int64_t n, int nt, int ntc, int ntiles, int blocks,
                           BlockMap map, double *partials);
-// ARD kernels with at least this many dimensions take it (below, the per-dimension work is small and the
-// scalar-row kernel of grad.hip is as fast)
-constexpr int ARD_MFMA_MIN_DIMS = 12;
+// (ARD kernels with at least `mfma_min_dims` dimensions take it -- option "ard_mfma_min_dims", default 1: measured at
+// N = 16384 it beats the scalar-row kernel of grad.hip at every D: 8: 1.16 -> 0.76 ms, 16: 1.91 -> 0.76, 32: 3.63 -> 1.01,
+// 64: 10.85 -> 2.50; 65 = never)
 
 // gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
 // gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}

@@ -805,10 +805,10 @@ int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
   // the last rank-nb updates of K^-1 run on s2; alpha is final (host-synchronised)
   if (h->prec == 32)
     launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->mat<float>(d->A), d->ldA(), h->n,
-                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout, h->radial1);
+                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout, h->radial1, h->ard_mfma_min);
   else
     launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->A, d->ldA(), h->n,
-                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout, h->radial1);
+                             (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout, h->radial1, h->ard_mfma_min);
   rec(h, EV_ALPHA, s2);
   wait(h, sc, EV_ALPHA);
   TRCHK(d->tr->allreduce(sc, h->gout, NACC, &e_));

@@ -226,7 +226,7 @@ int grad_reduce_blocks(int64_t npad) {
 template <class KT>
 static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                           const double *X, const double *alpha, const KT *Kinv, int64_t ld,
-                          int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
+                          int64_t n, int64_t npad, double *partials, double *out, bool radial1, int mfma_min) {
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
@@ -247,7 +247,7 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
                          alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
                          tl_batch.stride);                                                        \
   } while (0)
-  if (radial1 && ard_dims >= ARD_MFMA_MIN_DIMS)
+  if (radial1 && ard_dims > 0 && ard_dims >= mfma_min)
     // one radial term, many ARD length scales: distances and per-dimension sums on the matrix cores
     launch_grad_ard_mfma(s, p, ndim, X, alpha, Kinv, ld, n, nt, 0, ntiles, blocks, BlockMap(), partials);
   else if (ard_dims <= 0) GOGP_LAUNCH_GR(0, 0);
@@ -275,13 +275,13 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
-  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1);
+                        int64_t n, int64_t npad, double *partials, double *out, bool radial1, int mfma_min) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1, mfma_min);
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const float *Kinv, int64_t ld,
-                        int64_t n, int64_t npad, double *partials, double *out, bool radial1) {
-  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1);
+                        int64_t n, int64_t npad, double *partials, double *out, bool radial1, int mfma_min) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out, radial1, mfma_min);
 }
 
 int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
@@ -293,7 +293,7 @@ template <class KT>
 static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                                 const double *X, const double *alpha, const KT *Kinv, int64_t ld,
                                 int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                                double *out, bool radial1) {
+                                double *out, bool radial1, int mfma_min) {
   const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
@@ -307,7 +307,7 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
       hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                          Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
   } while (0)
-  if (radial1 && ard_dims >= ARD_MFMA_MIN_DIMS)
+  if (radial1 && ard_dims > 0 && ard_dims >= mfma_min)
     launch_grad_ard_mfma(s, p, ndim, X, alpha, Kinv, ld, n, nt, ntc, ntiles, blocks, map, partials);
   else if (ard_dims <= 0) GOGP_LAUNCH_GRL(0, 0);
   else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8, 0);
@@ -332,14 +332,14 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out, bool radial1) {
-  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1);
+                              double *out, bool radial1, int mfma_min) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1, mfma_min);
 }
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const float *Kinv, int64_t ld,
                               int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
-                              double *out, bool radial1) {
-  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1);
+                              double *out, bool radial1, int mfma_min) {
+  grad_reduce_local_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, mrows, ncols, map, partials, out, radial1, mfma_min);
 }
 
 // ---- gradient w.r.t. the inputs (full Observe form) ------------------------------

@@ -103,6 +103,19 @@ __global__ __launch_bounds__(256) void grad_ard_mfma_kernel(
       for (int d = 0; d < DP; ++d) s += src[d] * src[d];
       (tid < 64 ? nr : nc)[tid & 63] = s;
     }
+    // this lane's 16 elements of K^-1, requested before the products so that their latency hides behind
+    // them (padded matrix: every address of the tile is valid; inside the per-pair branch below the loads
+    // would go out one at a time, each waiting for the previous pair's arithmetic)
+    // (not at DP = 64: the 32 extra registers would take the instance past 256, and its 109 KB of LDS allow
+    // one workgroup per CU anyway)
+    constexpr bool PREFETCH = DP < 64 || sizeof(KT) == 4;
+    KT kv[4][4];
+    if (PREFETCH) {
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) kv[tb][v] = Kinv[(lr0 + 16 * w + fk + 4 * v) * ld + lc0 + 16 * tb + fr];
+    }
     // ---- S = Xs_r Xs_c^T: wave w owns rows 16 w .. 16 w + 15, the four 16-column blocks -----------------
     f64x4 sacc[4];
 #pragma unroll
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256) void grad_ard_mfma_kernel(
         if (gi < n && gj <= gi) {
           double r2 = nr[i] + ncj - 2.0 * sacc[tb][v];
           r2 = r2 > 0.0 ? r2 : 0.0;
-          const double wv = ai[i] * ajv - (double)Kinv[(lr0 + i) * ld + lc0 + j];
+          const double wv = ai[i] * ajv - (double)(PREFETCH ? kv[tb][v] : Kinv[(lr0 + i) * ld + lc0 + j]);
           const double wgt = (gj < gi) ? 2.0 * wv : wv;
           double f, dfdr2;
           radial_eval(kind, r2, f, dfdr2);

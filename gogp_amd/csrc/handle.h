@@ -85,6 +85,8 @@ struct gogp_handle {
   int superpanel_head = 3;     // > 0: super-panel width while more than head_remaining panels are to come
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
+  int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the
+                               // gradient on the matrix cores (grad_mfma.hip); 65: never
   int kinv_fused = -1;          // ... and accumulates K^-1 = sum_P Y_P Y_P^T behind it, one rank-k update
                                // per super-panel of Y (0: one LAUUM launch over the finished Y in Gradient; -1: by size)
   int inv_prio = 0;            // 0: the inverse's streams at normal priority; 1: its bulk updates (s2) low;

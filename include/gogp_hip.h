@@ -336,6 +336,16 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          the exact (fp64, recomputed) Gram matrix                    (default 1)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
  *                          mat.ConditionTolerance                                   (default 16)
+ *   "superpanel_head" 0..8, "head_remaining" >= 0   wider super-panels while more than head_remaining
+ *                          panels are still to come (the chain has slack there; bulk updates with a longer
+ *                          K are more efficient); 0 switches it off                       (default 3, 16)
+ *   "kinv_fused"   -1|0|1  K^-1 accumulated behind the triangular inverse as one rank-k update per
+ *                          super-panel of Y (1) or formed by one launch over the finished Y in
+ *                          gogp_gradient (0); -1: fused up to N = 10240                    (default -1)
+ *   "ktri"         1 | 0   panel solves skip the zero half of the (lower triangular) block inverse (default 1)
+ *   "ard_mfma_min_dims" 1..65  ARD kernels with one radial term and at least this many dimensions run
+ *                          the gradient reduction with distances and per-dimension sums on the matrix
+ *                          cores (grad_mfma.hip); 65: never                                 (default 1)
  *   "graph"        1 | 0   gogp_observe_gradient_candidates up to N = 1024: capture the launch
  *                          sequence into a hipGraph on its second identical use and replay it
  *                          (parameters and data may change, sizes may not)              (default 1)

@@ -283,12 +283,13 @@ def test_ard_gradient_many_dimensions_two_terms(gpmod, D, n):
 
 
 @pytest.mark.parametrize("kind", ["normal", "matern52"])
-@pytest.mark.parametrize("D,n", [(9, 900), (12, 900), (16, 2300), (17, 900), (24, 900), (32, 900), (33, 900), (40, 4200),
+@pytest.mark.parametrize("D,n", [(2, 700), (9, 900), (12, 900), (16, 2300), (17, 900), (24, 900), (32, 900), (33, 900), (40, 4200),
                                  (48, 700), (49, 1300), (64, 4200)])
 def test_ard_gradient_many_dimensions(gpmod, D, n, kind):
-    """ARD kernels with one radial term and 12 or more length scales take grad_mfma.hip: distances and the
-    per-dimension sums on the matrix cores (S = Xs Xs^T and P = G Xs per 64x64 tile), every D padded to a
-    multiple of 16; below 12 dimensions the scalar-row kernel of grad.hip.  n = 4200 gives every workgroup
+    """ARD kernels with one radial term take grad_mfma.hip: distances and the per-dimension sums on the
+    matrix cores (S = Xs Xs^T and P = G Xs per 64x64 tile), every D padded to a multiple of 16 (option
+    ard_mfma_min_dims = 65 selects the scalar-row kernel of grad.hip instead: second half of the test).
+    n = 4200 gives every workgroup
     several tiles, D = 16 / 32 / 48 / 64 are the exact pad sizes, 17 / 33 / 49 one past them.  Against the
     oracle, and bit-for-bit repeatable."""
     from oracle.oracle import FastOracle
@@ -309,6 +310,9 @@ def test_ard_gradient_many_dimensions(gpmod, D, n, kind):
     np.testing.assert_array_equal(grads[0], grads[1])
     np.testing.assert_array_equal(grads[0], grads[2])
     assert np.abs(grads[0] - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
+    g.set_option("ard_mfma_min_dims", 65)  # the scalar-row instances of grad.hip on the same data
+    g.Observe(x)
+    assert np.abs(g.Gradient() - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
     g.close()
 
 
