@@ -79,6 +79,9 @@ struct GemmGrid {
   // GEMM_RECT: B (nt*128 x K) is lower triangular (a block inverse: the panel solves L21 = A21 inv(L11)^T):
   // tile column tj only sums k < (tj + 1) * tile -- the rest of its rows of B is zero
   int ktri = 0;
+  // the launch sits on a dependency chain (panel solves, look-ahead updates): its waves raise their issue
+  // priority (s_setprio 3), so that on a CU they share with bulk workgroups their MFMAs go first
+  int prio = 0;
 };
 
 // Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of

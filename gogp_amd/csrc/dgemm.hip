@@ -56,6 +56,7 @@ struct GemmArgs {
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;
   int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
   int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
+  int prio;      // chain launch: s_setprio 3 (common.h: GemmGrid)
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
@@ -69,6 +70,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 __device__ __forceinline__ void load16_to_lds(const double *gsrc, double *lds_wave_base) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void raise_wave_priority() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);
 #endif
 }
 __device__ __forceinline__ void wait_vmcnt0() {
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile bases stay in SGPRs
+  if (g.prio) raise_wave_priority();
 
   // ---- tile assignment ----------------------------------------------------
   int t = blockIdx.x;
@@ -271,6 +278,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.Pr = g.Pc = 1;
   g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
   g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
+  g.prio = grid ? grid->prio : 0;
   g.bstride = tl_batch.stride;
   const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
@@ -352,6 +360,8 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // (a batched launch counts the tiles of all its candidates: together they fill the chip)
   const long total_tiles = (long)ntiles * nz;
   const bool small = (mode != GEMM_LAUUM) && (total_tiles < 384);
+  // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
+  if (g.prio == 1 && !small) g.prio = 0;
   if (small) {
     g.mt = mt * 2;
     g.nt = nt * 2;

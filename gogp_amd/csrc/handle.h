@@ -84,6 +84,7 @@ struct gogp_handle {
                                // preparation), interleaved with the Cholesky sweep
   int superpanel_head = 3;     // > 0: super-panel width while more than head_remaining panels are to come
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
+  int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
   int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the
                                // gradient on the matrix cores (grad_mfma.hip); 65: never

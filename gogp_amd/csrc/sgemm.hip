@@ -43,11 +43,17 @@ struct SGemmArgs {
   int rule, tpb_shift, rblk0, cblk0, pr, Pr, pc, Pc, beta0;  // GemmGrid, see dgemm.hip
   int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
   int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
+  int prio;      // chain launch: s_setprio 3 (common.h: GemmGrid)
 };
 
 __device__ __forceinline__ void sload16_to_lds(const float *gsrc, float *lds_wave_base) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void sraise_wave_priority() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(3);
 #endif
 }
 __device__ __forceinline__ void swait_vmcnt0() {
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (g.prio) sraise_wave_priority();
 
   int t = blockIdx.x;
   if (MODE != GEMM_LAUUM && !(MODE == GEMM_RECT && g.rule)) {  // XCD-aware remap (dgemm.hip)
@@ -226,6 +233,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
   g.Pr = g.Pc = 1;
   g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
   g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
+  g.prio = grid ? grid->prio : 0;
   if (grid && grid->rule) {
     g.rule = grid->rule;
     g.tpb_shift = grid->tpb_shift;
@@ -299,6 +307,8 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
       hipLaunchKernelGGL((__VA_ARGS__), (GRID), (BLOCK), 0, s, g);                         \
   } while (0)
   const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
+  // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
+  if (g.prio == 1 && !small) g.prio = 0;
   if (small) {  // 64x64 tiles for the skinny GEMMs of the panel chain
     g.mt = mt * 2;
     g.nt = nt * 2;
