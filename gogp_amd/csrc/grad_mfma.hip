@@ -261,12 +261,10 @@ static void launch_ard_mfma_t(hipStream_t s, const DevParams *p, int ndim, const
   const size_t lds = ard_mfma_lds(DP);
 #define GOGP_LAUNCH_AM(DPV)                                                                              \
   do {                                                                                                   \
-    static bool raised = false; /* > 64 KB of dynamic LDS needs the attribute once per instance */       \
-    if (!raised && lds > 65536) {                                                                         \
+    /* > 64 KB of dynamic LDS needs the attribute; set per launch (per device, cheap next to the kernel) */ \
+    if (lds > 65536)                                                                                      \
       (void)hipFuncSetAttribute((const void *)grad_ard_mfma_kernel<DPV, LOCAL, KT>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-      raised = true;                                                                                     \
-    }                                                                                                    \
     hipLaunchKernelGGL((grad_ard_mfma_kernel<DPV, LOCAL, KT>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, alpha, \
                        Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, bstride);                 \
   } while (0)

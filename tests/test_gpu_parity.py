@@ -800,7 +800,8 @@ def test_observe_gradient_batch_matches_single_calls(gpmod):
         g.close()
 
 
-@pytest.mark.parametrize("n,D,name", [(1200, 3, "matern32"), (700, 2, "periodic_sum"), (2100, 24, "ard"), (37, 1, "rbf")])
+@pytest.mark.parametrize("n,D,name", [(1200, 3, "matern32"), (700, 2, "periodic_sum"), (2100, 24, "ard"), (37, 1, "rbf"),
+                                      (600, 24, "ard")])  # ARD below N = 1024: the MFMA reduction inside the captured graph
 def test_candidates_in_one_launch_sequence_match_single_calls(gpmod, n, D, name):
     """gogp_observe_gradient_candidates: k parameter vectors in one launch sequence (candidate
     index on the grid's z axis) give bit for bit what Observe + Gradient return one at a time --
