@@ -19,7 +19,7 @@ def short(n):
 
 
 for path in sys.argv[1:]:
-    f = glob.glob(path + "/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(path + "/*/*_counter_collection.csv"), key=__import__("os").path.getmtime)
     rows = list(csv.DictReader(open(f)))
     if not rows:
         continue

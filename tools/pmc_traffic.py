@@ -7,7 +7,7 @@ library's build id)"""
 import collections, csv, glob, json, sys
 cfg, fdir, wdir, fam = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 def load(path, counter):
-    f = glob.glob(path + "/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(path + "/*/*_counter_collection.csv"), key=__import__("os").path.getmtime)
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(f)):
         if fam in r['Kernel_Name'] and r['Counter_Name'] == counter:

@@ -8,7 +8,8 @@
   serialised sum of GRBM_GUI_ACTIVE of its launches / XCDs / clock from the --pmc pass, where kernels
              run one at a time: a lower bound of the achieved rate.
 
-usage: roofline_from_profiles.py <N> <family> <peak TF/s> <kernel-trace dir> [<pmc dir>]  -> JSON on stdout
+usage: roofline_from_profiles.py <N> <family> <peak TF/s> <kernel-trace dir | .csv> [<pmc dir | .csv>]  -> JSON on stdout
+e.g.   python3 tools/roofline_from_profiles.py 16384 dgemm_nt_kernel 78.6 profiles/r03_c3_kernel_trace.csv
 """
 import csv, glob, json, sys
 
@@ -16,7 +17,8 @@ N, fam, peak, tdir = float(sys.argv[1]), sys.argv[2], float(sys.argv[3]), sys.ar
 pdir = sys.argv[5] if len(sys.argv) > 5 else None
 XCDS, CLOCK_HZ = 8, 2.4e9
 
-rows = list(csv.DictReader(open(glob.glob(tdir + "/*/*_kernel_trace.csv")[0])))
+trace = tdir if tdir.endswith(".csv") else max(glob.glob(tdir + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
+rows = list(csv.DictReader(open(trace)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 # an evaluation starts with the split Gram build (two gram_kernel launches)
 grams = [e for e in ev if "gram_kernel" in e[2]]
@@ -45,7 +47,7 @@ out["frac_union"] = out["achieved_tflops_union"] / peak
 span = (max(e for _, e, _ in ev) - min(s for s, _, _ in ev)) / 1e6
 out["trace_span_ms"] = span
 if pdir:
-    f = glob.glob(pdir + "/*/*_counter_collection.csv")[0]
+    f = pdir if pdir.endswith(".csv") else max(glob.glob(pdir + "/*/*_counter_collection.csv"), key=__import__("os").path.getmtime)
     gui, disp = 0.0, set()
     for r in csv.DictReader(open(f)):
         if fam in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":

@@ -1,7 +1,7 @@
 """Timeline of the panel chain inside the last evaluation of a kernel trace: for every diagonal-block
 kernel its start, duration, and what ran between the end of the previous one and its start."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
 rows = list(csv.DictReader(open(f)))
 def short(n):
     n = n.replace('void gogp::', '').replace('gogp::', '')

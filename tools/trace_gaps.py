@@ -1,6 +1,6 @@
 """Largest gaps (no dgemm kernel running) inside the last evaluation of a kernel trace."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 grams = [i for i, e in enumerate(ev) if 'gram_kernel' in e[2]]

@@ -6,7 +6,7 @@ import glob
 import sys
 
 path = sys.argv[1]
-f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
+f = max(glob.glob(path + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
 rows = list(csv.DictReader(open(f)))
 KEYS = ['dgemm_nt_kernel<0, 64>', 'dgemm_nt_kernel<1, 64>', 'dgemm_nt_kernel<0, 128>', 'dgemm_nt_kernel<1, 128>',
         'dgemm_nt_kernel<2, 128>', 'diag256', 'diag128', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'grad_final',
