@@ -151,3 +151,24 @@ def test_rank_plumbing_gloo_world2(tmp_path):
                         str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_reports_pmc_traffic_only_for_the_build_it_was_measured_on():
+    """profiles/r03_pmc_traffic.json carries the build id of the library it was measured on (gogp_version():
+    a hash of the library's sources); bench.py copies the number into roofline.traffic for that build only and
+    says why not otherwise -- a stale file must not look like a measurement of the current kernel."""
+    import json
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+    assert d["build"] and d["3"]["N"] == 16384 and d["3"]["bytes_per_launch"] > 1e8
+    e, why = bench.pmc_traffic(3, d["build"])
+    assert why is None and e["bytes_per_launch"] == d["3"]["bytes_per_launch"]
+    e, why = bench.pmc_traffic(3, "0123456789ab")
+    assert e is None and "stale" in why and d["build"] in why
+    e, why = bench.pmc_traffic(4, d["build"])
+    assert e is None and "no PMC pass" in why
+    # the version string of the built library ends in a 12-digit hex build id
+    from gogp_amd import _lib
+    v = _lib.lib().gogp_version().decode()
+    bid = v.split("build ")[-1]
+    assert len(bid) == 12 and all(c in "0123456789abcdef" for c in bid), v
