@@ -115,3 +115,31 @@ def test_bench_sharded_config_runs_the_optimiser_over_the_shards():
     assert "error" not in lb, lb
     assert lb["evaluations"] >= 2 and lb["lml_end"] >= lb["lml_start"]
     assert d["sharded_evaluation"]["lml_rel_diff_vs_single_gpu"] < 1e-4
+
+
+def test_phase_watchdog_names_rank_and_phase_and_exits_nonzero(tmp_path):
+    """A pre-flight phase that does not return (a hung ncclCommInitRank, a send/recv ring that never
+    completes) must end the process non-zero with the rank and the phase on stderr, and rank 0 still prints a
+    JSON line carrying the error -- the call that hangs sits in C with the GIL released, here a sleep."""
+    script = tmp_path / "wd.py"
+    script.write_text(
+        "import sys, time, json, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "out = os.fdopen(os.dup(1), 'w')\n"
+        "wd = bench.PhaseWatchdog(int(sys.argv[1]), out, {'line': {'metric': 'm', 'value': None}})\n"
+        "with wd.phase('quick phase', 5):\n"
+        "    pass\n"
+        "with wd.phase('grouped send/recv ring (rank -> rank+1)', 1):\n"
+        "    time.sleep(30)\n"
+        "print('not reached')\n" % ROOT)
+    for rank in (0, 3):
+        r = subprocess.run([sys.executable, str(script), str(rank)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 4
+        assert "rank %d" % rank in r.stderr and "grouped send/recv ring" in r.stderr and "1 s" in r.stderr
+        assert "not reached" not in r.stdout
+        if rank == 0:
+            d = _one_line(r.stdout)
+            assert "grouped send/recv ring" in d["error"] and d["value"] is None
+        else:
+            assert r.stdout.strip() == ""
