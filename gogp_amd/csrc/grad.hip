@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
   }
 }
 
+#ifndef GOGP_GRAD_KERNEL_ONLY  // (the hook library includes this file for the reduction kernel template alone)
 // out[q] = sum over blocks of partials[b][q]; one workgroup per slot q, fixed
 // summation tree (bitwise reproducible)
 __global__ __launch_bounds__(256) void grad_final_kernel(const double *__restrict__ partials,
@@ -453,5 +454,7 @@ void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
     for (int d0 = 0; d0 < ndim; d0 += 32) GOGP_LAUNCH_XG(32, d0);
 #undef GOGP_LAUNCH_XG
 }
+
+#endif  // GOGP_GRAD_KERNEL_ONLY
 
 }  // namespace gogp

@@ -128,5 +128,21 @@ def test_the_config5_gradient_instance_is_lean(kernels):
 def test_hook_library_kernels_spill_nothing_either():
     if not os.path.exists(HOOKS):
         pytest.skip("libgogp_testhooks.so not built")
+    # diagnostic kernels are over the limits on purpose (gogp_test_grad64, tools/agpr_probe.py): the whole
+    # pre-round-2 gradient source in namespace gogp_old (its sharded 64-accumulator instance is the one round 2
+    # removed from the product for wrong sums), that instance rebuilt from today's template, and the register
+    # scrub kernel that owns the whole register file of its SIMD lane
+    on_purpose = ("gogp_old::", "grad_reduce_kernel<64, true, double, false>", "scrub_regs_kernel")
+    seen = set()
     for k in codeobj_audit.kernels(HOOKS):
+        hit = [n for n in on_purpose if n in k["name"]]
+        if hit:
+            seen.add(hit[0])
+            continue
         assert k.get("vgpr_spill_count", 0) == 0 and k["vgpr_count"] <= 256, k["name"]
+    assert seen == set(on_purpose)
+
+
+def test_the_product_library_holds_no_diagnostic_kernel(kernels):
+    for k in kernels:
+        assert "gogp_old" not in k["name"] and "scrub_regs" not in k["name"], k["name"]

@@ -1,0 +1,220 @@
+// common.h -- shared declarations of libgogp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "gogp_hip.h"
+
+namespace gogp {
+
+// Blocking constants.  TILE is the GEMM workgroup tile and the diagonal-block
+// size; PANEL is the rank of one trailing update (2 diagonal blocks).
+constexpr int TILE = 128;
+constexpr int PANEL = 256;
+constexpr int GEMM_BK = 16;
+
+// Device-side copy of the kernel description + current hyperparameters.
+// Lives in device memory; every field is read with wave-uniform (scalar) loads.
+struct DevParams {
+  int ndim, nterms, ns, nn;
+  int kind[GOGP_MAX_TERMS];
+  int ard[GOGP_MAX_TERMS];
+  double c[GOGP_MAX_TERMS];  // output scale of the term (1 if it has none)
+  double w[GOGP_MAX_TERMS];  // PERIODIC: pi / (period_mult * theta_p)
+  double inv_len[GOGP_MAX_TERMS][GOGP_MAX_NDIM];  // 1/l_d (all equal unless ard)
+  double noise_var;  // value added on the diagonal
+  double dnoise;     // d noise_var / d log(std)  (0 for ConstantNoise)
+};
+
+// Accumulator slots of the fused gradient reduction (see grad.hip):
+//   slot 3*t+0: d/dlog scale of term t, 3*t+1: d/dlog len (non-ARD),
+//   3*t+2: d/dlog period; slot 12: trace(W) (noise); 16+d: ARD length d.
+constexpr int ACC_TRACE = 3 * GOGP_MAX_TERMS;
+constexpr int ACC_ARD0 = 16;
+constexpr int NACC = ACC_ARD0 + GOGP_MAX_NDIM;
+
+struct GemmProfile {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  double flops = 0;
+  int64_t launches = 0;
+};
+
+// Tile filter of the tile kernel in a sharded (2-D block-cyclic) evaluation (GemmArgs in
+// dgemm.hip): the launch covers LOCAL 128-tiles starting at local row / column block
+// rblk0 / cblk0 (a distribution block = 2^tpb_shift tiles); this rank sits at (pr, pc) of
+// the Pr x Pc process grid.  rule 1: keep the tiles of the GLOBAL lower triangle; rule 2:
+// the same, and tiles of global row block beta0 overwrite C (beta = 0) while the others
+// accumulate (beta = 1): the rank-k updates of K^-1 = Y Y^T.
+struct GemmGrid {
+  int rule = 0, tpb_shift = 0, rblk0 = 0, cblk0 = 0, pr = 0, Pr = 1, pc = 0, Pc = 1, beta0 = -1;
+};
+
+// Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of
+// nb = 2^nb_shift rows / columns; local row block bi of the rank at grid row pr is global block
+// bi * Pr + pr (columns: pc, Pc).
+struct BlockMap {
+  int nb_shift = 9, pr = 0, Pr = 1, pc = 0, Pc = 1;
+  __host__ __device__ long grow(long lrow) const {
+    const long nbm = (1L << nb_shift) - 1;
+    return ((((lrow >> nb_shift) * Pr + pr)) << nb_shift) + (lrow & nbm);
+  }
+  __host__ __device__ long gcol(long lcol) const {
+    const long nbm = (1L << nb_shift) - 1;
+    return ((((lcol >> nb_shift) * Pc + pc)) << nb_shift) + (lcol & nbm);
+  }
+};
+
+// ---- launchers implemented in the .hip files ------------------------------
+enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2,
+                // GEMM_RECT whose tiles in strictly upper 256x256 blocks (block column > block row,
+                // counted from the C origin) are skipped: several adjacent block columns updated
+                // "each from its own diagonal block down" in ONE launch
+                GEMM_TRAP = 3 };
+
+// C(mt*128 x nt*128) = beta*C + alpha * A * B^T, row-major, K multiple of 16.
+// GEMM_LOWER: square tile grid mt x mt, only tiles ti >= tj.
+// GEMM_LAUUM: lower tiles; tile (ti,tj) sums k over [ti*128, K).
+void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K,
+                     double alpha, const double *A, int64_t lda, const double *B,
+                     int64_t ldb, double beta, double *C, int64_t ldc,
+                     GemmProfile *prof, const GemmGrid *grid = nullptr);
+
+// fp32 path (BASELINE config 5): the same launchers overloaded on the MATRIX element type.
+// Inputs, vectors (y, z, alpha) and every reduction stay fp64; only the N x N matrices
+// (K / L / Y / K^-1, the block inverses, the Produce workspaces) are float.
+void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha, const double *A,
+                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
+                    GemmProfile *prof, const GemmGrid *grid = nullptr);  // = launch_dgemm_nt
+void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha, const float *A,
+                    int64_t lda, const float *B, int64_t ldb, double beta, float *C, int64_t ldc,
+                    GemmProfile *prof, const GemmGrid *grid = nullptr);  // sgemm.hip
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, float *K, int64_t ld,
+                             int64_t wcols);
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, float *KsT, int64_t ld);
+void launch_trsv_fwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv, int b, int nblk,
+                          double *y, double *z);
+void launch_trsv_bwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv, int b, int nblk,
+                          double *zwork, double *alpha);
+void launch_lml_scalars(hipStream_t s, const float *L, int64_t ld, const double *z, const double *y,
+                        const double *alpha, int64_t n, double *scalars);
+void launch_alpha_from_y(hipStream_t s, const float *Y, int64_t ld, const double *z, int64_t npad,
+                         double *alpha);
+void launch_rownorm_dot(hipStream_t s, const float *V, int64_t ld, const double *vec, int64_t ncols,
+                        int64_t m, double *dot, double *sq);
+void launch_zero_upper_blocks(hipStream_t s, float *R, int64_t ld, int64_t npad);
+void launch_zero_block(hipStream_t s, float *B, int64_t ld, int64_t rows, int64_t cols);
+void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld);
+void launch_extract_lower(hipStream_t s, const float *L, int64_t ld, int64_t n, double *out);
+void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, float *L, int64_t ld);
+void launch_convert_block(hipStream_t s, const float *src, int64_t lds_, double *dst, int64_t ldd, int rows,
+                          int cols);
+void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float *dst, int64_t ldd, int rows,
+                          int cols);
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims, const double *X,
+                        const double *alpha, const float *Kinv, int64_t ld, int64_t n, int64_t npad,
+                        double *partials, double *out);
+
+void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                       int64_t n, int64_t npad, double *K, int64_t ld);
+// Local tiles (mrows x ncols) of a 2-D block-cyclic Gram matrix: tiles of the global lower
+// triangle get kernel values (identity padding for rows >= n), distribution blocks strictly
+// above the diagonal are zero-filled (the work area R of the triangular inverse).
+void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                       int64_t mrows, int64_t ncols, BlockMap map, double *K, int64_t ld);
+void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
+                             const double *X, int64_t n, int64_t npad, double *K, int64_t ld,
+                             int64_t wcols);
+// KsT (mpad x npad): KsT[j][i] = k(x_i, z_j); zero for i >= n or j >= m.
+void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
+                  int64_t npad, const double *Z, int64_t m, int64_t mpad, double *KsT,
+                  int64_t ld);
+// r = y - K v with K recomputed in fp64 on the fly (iterative refinement of alpha on the fp32 path);
+// part: nslab * npad doubles of scratch
+void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n, int64_t npad,
+                     const double *v, const double *y, double *part, int nslab, double *r);
+void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
+                  double *prior);
+
+// forward / backward substitution steps with the stored 256x256 block inverses
+// (b, nb count 256-blocks)
+void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
+                          int b, int nblk, double *y, double *z);
+void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
+                          int b, int nblk, double *zwork, double *alpha);
+
+// scalars[0] = sum_i 2 log L_ii, scalars[1] = sum z_i^2, scalars[2] = sum y_i alpha_i
+// (i < n; the last only when alpha != nullptr)
+void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
+                        const double *y, const double *alpha, int64_t n, double *scalars);
+// potrf + dense inverse of one 256x256 diagonal block (diag256.hip); Dinv has
+// leading dimension 256.  A (ld): in: lower triangle of the block; Lout (ldl): out: lower
+// factor (upper zeroed); Dinv: out: dense inverse of the factor (upper zero).  info: device
+// int64, set to (row0+j+1) at the first non-positive pivot with row0+j < nvalid (first
+// failure wins).
+void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                    double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+// the same with Dinv written into a 256x256 sub-block of a matrix of leading dimension 512
+void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
+                          double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
+void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
+                       int64_t ld);
+void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,
+                  double *sigma);
+int grad_reduce_blocks(int64_t npad);
+
+// fused gradient reduction over lower tiles of Kinv; out: NACC doubles
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const double *Kinv, int64_t ld, int64_t n,
+                        int64_t npad, double *partials, double *out);
+// the same over the LOCAL tiles (mrows x ncols, leading dimension ld) of a 2-D block-cyclic
+// K^-1: tiles of the global lower triangle only; `partials` needs grad_reduce_blocks_local
+int grad_reduce_blocks_local(int64_t mrows, int64_t ncols);
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out);
+
+// gradient w.r.t. the inputs: mirrors K^-1 to the upper triangle, then
+// gx[i][d] = sum_j (alpha_i alpha_j - Kinv_ij) dk(x_i,x_j)/dx_{i,d}
+void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                  const double *alpha, double *Kinv, int64_t ld, int64_t n, int64_t npad,
+                  double *gx);
+
+// dot_j = sum_i V[j][i] vec_i ; sq_j = sum_i V[j][i]^2  (either output may be null)
+void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double *vec,
+                        int64_t ncols, int64_t m, double *dot, double *sq);
+
+void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad);
+void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
+                         int64_t npad, double *alpha);
+void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
+void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
+void launch_fill(hipStream_t s, double *p, int64_t count, double v);
+void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
+void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b
+// helpers of the sharded evaluation (solve.hip)
+void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
+                         int n);
+void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
+                        int first, int stride);
+int64_t chunk_tdot_scratch(int64_t max_rows, int nb);  // doubles of `part` scratch
+void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
+                       double *part, double *out);
+void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
+                        const double *z, double *out);
+void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
+                         double *acc);
+void launch_sumsq_info(hipStream_t s, const double *z, int64_t n, const long long *info, double *out);
+void launch_info_to_double(hipStream_t s, const long long *info, double *out);
+void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n,
+                          double *out);
+
+}  // namespace gogp

@@ -1,0 +1,304 @@
+// grad.hip -- fused hyperparameter-gradient reduction (HBM-read-bound).
+//
+// Reference: gp.GP.Gradient (gp/gp.go:418-499) forms, PER PARAMETER p, the dense
+// products r0 = (alpha alpha^T) dK_p and r1 = K^-1 dK_p and takes
+// 1/2 tr(r0 - r1) (gp/gp.go:476-485), with dK_p = theta_p dK/dtheta_p built per
+// pair by the AD tape during absorb (gp/gp.go:113-117,137-142).  Since
+// tr(M dK) = sum_ij M_ij dK_ij for symmetric matrices this equals
+//     grad_p = 1/2 sum_ij W_ij dK_p,ij ,   W = alpha alpha^T - K^-1,
+// which is what this kernel evaluates in ONE pass over the lower triangle of
+// K^-1, recomputing k(x_i,x_j) and its log-parameter derivatives on the fly
+// (no dK matrix is ever stored).  Off-diagonal elements count twice.
+//
+// Output: NACC slot sums (see common.h); the host maps slots to theta indices.
+#include "kern_eval.h"
+
+namespace gogp {
+
+constexpr int GR_BLOCKS_MAX = 2048;
+
+// LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
+// grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
+// KT: element type of K^-1 (float on the fp32 path; all sums are fp64 either way).
+template <int ARD_D, bool LOCAL, class KT>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(
+    const DevParams *__restrict__ Pp, const double *__restrict__ X,
+    const double *__restrict__ alpha, const KT *__restrict__ Kinv, long ld, long n, int nt,
+    int ntiles, double *__restrict__ partials, int ntc, BlockMap map) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Ri = sm;              // [64][D]
+  double *CjT = sm + 64 * D;    // [D][64]
+  double *ai = sm + 128 * D;    // [64]
+  double *aj = ai + 64;         // [64]
+  double *red = aj + 64;        // [4][NACC]
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+
+  double acc[ACC_TRACE + 1];
+#pragma unroll
+  for (int q = 0; q <= ACC_TRACE; ++q) acc[q] = 0.0;
+  double ard[ARD_D > 0 ? ARD_D : 1];
+#pragma unroll
+  for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) ard[q] = 0.0;
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int ti, tj;
+    long r0, c0, lr0, lc0;
+    if (LOCAL) {
+      ti = t / ntc;
+      tj = t - ti * ntc;
+      lr0 = (long)ti * 64;
+      lc0 = (long)tj * 64;
+      r0 = map.grow(lr0);
+      c0 = map.gcol(lc0);
+      if (c0 > r0) continue;  // workgroup-uniform: tile of the global upper triangle
+    } else {
+      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 > t) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      tj = t - ti * (ti + 1) / 2;
+      lr0 = r0 = (long)ti * 64;
+      lc0 = c0 = (long)tj * 64;
+    }
+    __syncthreads();  // previous tile's readers are done
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int r = idx / D, d = idx - r * D;
+      Ri[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
+      CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+    }
+    if (tid < 64) ai[tid] = (r0 + tid < n) ? alpha[r0 + tid] : 0.0;
+    else if (tid < 128) aj[tid - 64] = (c0 + tid - 64 < n) ? alpha[c0 + tid - 64] : 0.0;
+    __syncthreads();
+    const long gj = c0 + tx;
+    const double *cj = CjT + tx;
+    const double ajv = aj[tx];
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = ty * 16 + rr;
+      const long gi = r0 + r;
+      if (gi < n && gj <= gi) {
+        const double w = ai[r] * ajv - (double)Kinv[(lr0 + r) * ld + lc0 + tx];
+        const double wgt = (gj < gi) ? 2.0 * w : w;
+        const double *ri = Ri + r * D;
+        simil_grad_accum<ARD_D>(
+            P, [&](int d) { return ri[d]; }, [&](int d) { return cj[d * 64]; }, wgt, acc, ard);
+        if (gi == gj) acc[ACC_TRACE] += w;
+      }
+    }
+  }
+
+  // ---- block reduction: wave shuffles, then 4 waves through LDS -------------
+  __syncthreads();
+  const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+  for (int q = 0; q <= ACC_TRACE; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wid * NACC + q] = v;
+  }
+  if (ARD_D > 0) {
+#pragma unroll
+    for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) {
+      double v = ard[q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wid * NACC + ACC_ARD0 + q] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NACC) {
+    double v = 0.0;
+    const bool live = (tid <= ACC_TRACE) || (tid >= ACC_ARD0 && tid < ACC_ARD0 + ARD_D);
+    if (live) v = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+    partials[(long)blockIdx.x * NACC + tid] = v;
+  }
+}
+
+// out[q] = sum over blocks of partials[b][q]; one workgroup per slot q, fixed
+// summation tree (bitwise reproducible)
+__global__ __launch_bounds__(256) void grad_final_kernel(const double *__restrict__ partials,
+                                                         int nblocks, double *__restrict__ out) {
+  __shared__ double red[4];
+  const int q = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(long)b * NACC + q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[q] = red[0] + red[1] + red[2] + red[3];
+}
+
+int grad_reduce_blocks(int64_t npad) {
+  const int nt = (int)(npad / 64);
+  const long ntiles = (long)nt * (nt + 1) / 2;
+  return (int)(ntiles < GR_BLOCKS_MAX ? ntiles : GR_BLOCKS_MAX);
+}
+
+template <class KT>
+static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                          const double *X, const double *alpha, const KT *Kinv, int64_t ld,
+                          int64_t n, int64_t npad, double *partials, double *out) {
+  const int nt = (int)(npad / 64);
+  const int ntiles = nt * (nt + 1) / 2;
+  const int blocks = grad_reduce_blocks(npad);
+  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+#define GOGP_LAUNCH_GR(AD)                                                                      \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap())
+  if (ard_dims <= 0) GOGP_LAUNCH_GR(0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GR(8);
+  else if (ard_dims <= 16) GOGP_LAUNCH_GR(16);
+  else if (ard_dims <= 32) GOGP_LAUNCH_GR(32);
+  else GOGP_LAUNCH_GR(64);
+#undef GOGP_LAUNCH_GR
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+}
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                        int64_t n, int64_t npad, double *partials, double *out) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
+}
+void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                        const double *X, const double *alpha, const float *Kinv, int64_t ld,
+                        int64_t n, int64_t npad, double *partials, double *out) {
+  grad_reduce_t(s, p, ndim, ard_dims, X, alpha, Kinv, ld, n, npad, partials, out);
+}
+
+int grad_reduce_blocks_local(int64_t mrows, int64_t ncols) {
+  const long ntiles = (long)(mrows / 64) * (long)(ncols / 64);
+  return (int)(ntiles < GR_BLOCKS_MAX ? (ntiles > 0 ? ntiles : 1) : GR_BLOCKS_MAX);
+}
+
+void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
+                              const double *X, const double *alpha, const double *Kinv, int64_t ld,
+                              int64_t n, int64_t mrows, int64_t ncols, BlockMap map, double *partials,
+                              double *out) {
+  const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
+  const int ntiles = nt * ntc;
+  const int blocks = grad_reduce_blocks_local(mrows, ncols);
+  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+#define GOGP_LAUNCH_GRL(AD)                                                                       \
+  hipLaunchKernelGGL((grad_reduce_kernel<AD, true, double>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+                     Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map)
+  if (ard_dims <= 0) GOGP_LAUNCH_GRL(0);
+  else if (ard_dims <= 8) GOGP_LAUNCH_GRL(8);
+  else if (ard_dims <= 16) GOGP_LAUNCH_GRL(16);
+  else if (ard_dims <= 32) GOGP_LAUNCH_GRL(32);
+  else GOGP_LAUNCH_GRL(64);
+#undef GOGP_LAUNCH_GRL
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out);
+}
+
+// ---- gradient w.r.t. the inputs (full Observe form) ------------------------------
+// gp/gp.go:118-129 builds one dense dK per input coordinate (N*D matrices of N x N);
+// since dK^{(i,d)} has only row/column i non-zero,
+//     dLML/dx_{i,d} = 1/2 tr(W dK^{(i,d)}) = sum_j W_ij dk(x_i,x_j)/dx_{i,d},
+// one pass over the FULL symmetric W = alpha alpha^T - K^-1 (the lower triangle of
+// K^-1 is mirrored first).  One workgroup per 64 rows; 4 threads share a row and
+// split each 64-column tile; fixed-order reductions.
+
+// upper 32x32 tiles <- transpose of the lower ones (diagonal 128-blocks are
+// already full from the LAUUM tile kernel)
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ A, long ld, int nt32) {
+  __shared__ double tile[32][33];
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  if (ti == tj || ti >= nt32) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = A[(long)(ti * 32 + ty + r) * ld + tj * 32 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) A[(long)(tj * 32 + ty + r) * ld + ti * 32 + tx] = tile[tx][ty + r];
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void xgrad_kernel(const DevParams *__restrict__ Pp,
+                                                    const double *__restrict__ X,
+                                                    const double *__restrict__ alpha,
+                                                    const double *__restrict__ Kinv, long ld,
+                                                    long n, long npad, double *__restrict__ gx) {
+  extern __shared__ double sm[];
+  const DevParams &P = *Pp;
+  const int D = P.ndim;
+  double *Xi = sm;               // [64][D]
+  double *Xj = Xi + 64 * D;      // [64][D]
+  double *T = Xj + 64 * D;       // [64][65]  W tile
+  double *aj = T + 64 * 65;      // [64]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * 64;
+  const int r = tid >> 2, q = tid & 3;
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int rr = idx / D, d = idx - rr * D;
+    Xi[idx] = (r0 + rr < n) ? X[(r0 + rr) * D + d] : 0.0;
+  }
+  const double ai = (r0 + r < n) ? alpha[r0 + r] : 0.0;
+  double acc[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) acc[d] = 0.0;
+  const double *xi = Xi + r * D;
+  for (long c0 = 0; c0 < npad; c0 += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int rr = idx / D, d = idx - rr * D;
+      Xj[idx] = (c0 + rr < n) ? X[(c0 + rr) * D + d] : 0.0;
+    }
+    if (tid < 64) aj[tid] = (c0 + tid < n) ? alpha[c0 + tid] : 0.0;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int rr = idx >> 6, cc = idx & 63;
+      T[rr * 65 + cc] = Kinv[(r0 + rr) * ld + c0 + cc];
+    }
+    __syncthreads();
+    if (r0 + r < n) {
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = q * 16 + jj;
+        if (c0 + j < n && c0 + j != r0 + r) {
+          const double W = ai * aj[j] - T[r * 65 + j];
+          const double *xj = Xj + j * D;
+          simil_xgrad_accum<DMAX>(
+              P, [&](int d) { return xi[d]; }, [&](int d) { return xj[d]; }, W, acc);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    double v = acc[d];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    if (q == 0 && d < D && r0 + r < n) gx[(r0 + r) * D + d] = v;
+  }
+}
+
+void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
+                  const double *alpha, double *Kinv, int64_t ld, int64_t n, int64_t npad,
+                  double *gx) {
+  const int nt32 = (int)(npad / 32);
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, s, Kinv,
+                     (long)ld, nt32);
+  const size_t lds = (size_t)(128 * ndim + 64 * 65 + 64) * sizeof(double);
+  const dim3 grid((unsigned)(npad / 64));
+  // above 64 KB of dynamic LDS (D > 32) the limit has to be raised explicitly
+#define GOGP_LAUNCH_XG(DM)                                                                     \
+  do {                                                                                         \
+    if (lds > 64 * 1024)                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xgrad_kernel<DM>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+    hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
+                       (long)n, (long)npad, gx);                                               \
+  } while (0)
+  if (ndim <= 4) GOGP_LAUNCH_XG(4);
+  else if (ndim <= 8) GOGP_LAUNCH_XG(8);
+  else if (ndim <= 16) GOGP_LAUNCH_XG(16);
+  else if (ndim <= 32) GOGP_LAUNCH_XG(32);
+  else GOGP_LAUNCH_XG(64);
+#undef GOGP_LAUNCH_XG
+}
+
+}  // namespace gogp
