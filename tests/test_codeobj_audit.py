@@ -29,23 +29,8 @@ import codeobj_audit  # noqa: E402
 LIB = os.path.join(ROOT, "gogp_amd", "libgogp_hip.so")
 HOOKS = os.path.join(ROOT, "gogp_amd", "libgogp_testhooks.so")
 
-SGPR_SPILL_LIMIT = 48
-#: kernel-name regex -> allowed SGPR spill count, with the reason
-SGPR_SPILL_ALLOW = {
-    # the chain's diagonal-block kernel with potrf128_lds inlined: measured 7 % faster than the out-of-line
-    # call hipcc chooses by itself (313,996 vs 336,912 cycles per 256-block), which also needs a 20-byte
-    # private segment for the callee-saved VGPRs; the spilled SGPRs are hoisted LDS offsets of the unrolled
-    # 16-column steps
-    r"diag256_kernel<true, false, \d+>": 480,
-    # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor
-    r"diag256_kernel<false, false, \d+>": 260,
-    # multi-term / periodic kernels keep the per-pair loop: kind, scale, period and length tables of up to
-    # four terms stay live across it.  Not on any BASELINE configuration (those are single radial terms)
-    r"grad_reduce_kernel<\d+, (true|false), (double|float), false>": 80,
-    # gradient w.r.t. the inputs (full Observe form, the anynoise / warpedtime case studies): N <= a few
-    # hundred in the reference; 32 per-dimension accumulators
-    r"xgrad_kernel<32>": 100,
-}
+SGPR_SPILL_LIMIT = codeobj_audit.SGPR_SPILL_LIMIT
+SGPR_SPILL_ALLOW = codeobj_audit.SGPR_SPILL_ALLOW  # the limits live beside the parser: the build checks them too
 
 
 @pytest.fixture(scope="module")
@@ -66,10 +51,7 @@ def test_every_hot_kernel_is_present(kernels):
         assert want in names, want
 
 
-#: kernels that may use AGPRs: MFMA accumulators the compiler keeps there (written by MFMA under the full
-#: EXEC mask and recomputed per tile -- never a parking place for values that live across divergent
-#: trips, which is what the removed instances' spill copies were)
-AGPR_ALLOW = {r"grad_ard_mfma_kernel<\d+, (true|false), (double|float)>": 64}
+AGPR_ALLOW = codeobj_audit.AGPR_ALLOW
 
 
 def test_no_vgpr_spills_no_scratch_no_agprs(kernels):
@@ -82,6 +64,14 @@ def test_no_vgpr_spills_no_scratch_no_agprs(kernels):
            for k in kernels
            if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0) or not agprs_ok(k)]
     assert not bad, "kernels with VGPR spills / scratch / AGPRs (name, vgpr spills, scratch bytes, agprs): %r" % bad
+
+
+def test_the_build_time_check_agrees(kernels):
+    """`make audit` / __graft_entry__.build() run codeobj_audit.violations(): the same limits in one call."""
+    assert codeobj_audit.violations(kernels) == []
+    broken = [dict(kernels[0], vgpr_spill_count=3, vgpr_count=300)]
+    what = " ".join(w for _, w in codeobj_audit.violations(broken))
+    assert "3 VGPR spills" in what and "300 VGPRs" in what
 
 
 def test_at_most_256_vgprs(kernels):
