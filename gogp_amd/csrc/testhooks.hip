@@ -1,6 +1,7 @@
 // testhooks.hip -- measurement / diagnostic entry points (include/gogp_testhooks.h).
 // Built into gogp_amd/libgogp_testhooks.so, which links libgogp_hip.so and calls its
 // internal launchers; none of this is part of the product ABI (include/gogp_hip.h).
+#include <cstdlib>
 #include <stdio.h>
 
 #include "common.h"
@@ -202,12 +203,15 @@ extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, 
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
+  // GOGP_BENCH_GEMM_LD0=1: every operand row aliases row 0 (lda = ldb = 0): all operand loads hit in the
+  // caches -- the kernel's rate with memory latency taken out (diagnostic)
+  const int64_t ld = getenv("GOGP_BENCH_GEMM_LD0") ? 0 : Kld;
   for (int w = 0; w < 2; ++w)
-    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, nullptr);
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, ld, dB, ld, beta, dC, N, nullptr);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0, 0);
   for (int r = 0; r < reps; ++r)
-    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, Kld, dB, Kld, beta, dC, N, &pf);
+    launch_dgemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, dA, ld, dB, ld, beta, dC, N, &pf);
   (void)hipEventRecord(e1, 0);
   e = hipEventSynchronize(e1);
   float ms = 0.f;
