@@ -522,8 +522,9 @@ def main():
         achieved = (per_rank * steps / (gemm_busy_ms * 1e-3) / 1e12 if gemm_busy_ms > 0 else 0.0)
         try:
             peak_cal = G.mfma_f64_peak(20000, local_rank) if prec == 64 else None
+            peak_cal32 = G.mfma_f32_peak(20000, local_rank) if prec == 32 else None
         except Exception:
-            peak_cal = None
+            peak_cal = peak_cal32 = None
         out = {
             "metric": "GP.Observe+Gradient evals/sec (%s) at N=%d D=%d" % (
                 "fp64" if dtype == "f64" else "fp32", N, D),
@@ -566,13 +567,14 @@ def main():
                 "launch_concurrency": gemm_ms / gemm_busy_ms if gemm_busy_ms > 0 else None,
                 "launched_flops_per_step": gemm_flops / max(1, steps),
                 "peak_calibrated_mfma_f64": peak_cal,
+                "peak_calibrated_mfma_f32": peak_cal32,
                 "note": "achieved = N^3 algorithmic flop per step / HIP-event-timed busy time of the "
                         "kernel per step (union of its launch intervals: launches overlap on several "
                         "streams; rocprofv3 --stats sums them, see sum_of_launch_durations_ms_per_step = "
                         "avg_launch_ms x launches_per_step); frac_wall = the same flop / wall time per "
                         "step (a lower bound that needs no event arithmetic); peak = 78.6 TFLOP/s fp64 spec "
-                        "(157.3 fp32 matrix); peak_calibrated = sustained v_mfma_f64 issue-rate microbenchmark "
-                        "on this device",
+                        "(157.3 fp32 matrix); peak_calibrated = sustained v_mfma_f64 (fp32 path: v_mfma_f32_32x32x2) "
+                        "issue-rate microbenchmark on this device",
             },
         }
         version = G._lib.lib().gogp_version().decode()

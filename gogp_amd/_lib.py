@@ -84,6 +84,7 @@ SYMBOLS = [
 #: diagnostic hooks for tests/, tools/ and bench.py -- not part of the product ABI)
 HOOK_SYMBOLS = [
     ("gogp_mfma_f64_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
+    ("gogp_mfma_f32_peak", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]),
     ("gogp_bench_gemm", ctypes.c_int,
      [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_int, _dp, _dp]),
     ("gogp_test_diag256", ctypes.c_int,

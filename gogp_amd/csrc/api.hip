@@ -554,8 +554,11 @@ static inline int chain_prio_of(const gogp_handle *h) {
   return h->chain_prio < 0 ? (h->npad <= 6144 ? 1 : 0) : h->chain_prio;
 }
 
+// superpanel_head = -1 (default): 3 panels in fp64, 4 on the fp32 path, whose bulk updates run twice as fast
+// beside the same fp64 diagonal-block chain (N = 32768: 311.6 -> 309.4 ms, N = 65536: 2322 -> 2303 ms; 6: 312.5)
 static inline int superpanel_width(const gogp_handle *h, int npanel, int P0) {
-  const int sw = (h->superpanel_head > 0 && npanel - P0 > h->head_remaining) ? h->superpanel_head : h->superpanel;
+  const int head = h->superpanel_head < 0 ? (h->prec == 32 ? 4 : 3) : h->superpanel_head;
+  const int sw = (head > 0 && npanel - P0 > h->head_remaining) ? head : h->superpanel;
   return (npanel - P0 < sw) ? npanel - P0 : sw;
 }
 
@@ -1776,7 +1779,7 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     return GOGP_OK;
   }
   if (strcmp(name, "superpanel_head") == 0) {
-    if (value < 0 || value > 8) return fail(h, GOGP_EARG, "superpanel_head must be 0..8");
+    if (value < -1 || value > 8) return fail(h, GOGP_EARG, "superpanel_head must be -1..8");
     h->superpanel_head = (int)value;
     return GOGP_OK;
   }

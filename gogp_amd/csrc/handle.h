@@ -82,7 +82,7 @@ struct gogp_handle {
   int superpanel = 2;          // 256-wide panels per trailing update (K = 256*superpanel)
   int eager = 1;               // Observe also runs the triangular inverse (gradient
                                // preparation), interleaved with the Cholesky sweep
-  int superpanel_head = 3;     // > 0: super-panel width while more than head_remaining panels are to come
+  int superpanel_head = -1;    // > 0: super-panel width while more than head_remaining panels are to come; -1: 3 (fp64) / 4 (fp32)
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)

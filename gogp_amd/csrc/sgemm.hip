@@ -62,14 +62,18 @@ __device__ __forceinline__ void swait_vmcnt0() {
 #endif
 }
 
-// BT = workgroup tile (128 or 64); 4 waves as 2x2, each (BT/2)x(BT/2) outputs = MT x MT MFMA
-// 32x32 tiles, MT = BT/64.
-template <int MODE, int BT>
-__global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
-  constexpr int MT = BT / 64;
-  constexpr int WT = BT / 2;
-  constexpr int NQ = BT * 8 / 256;  // staging loads per thread per operand
-  constexpr int SROWS = 32;         // rows one staging pass covers (256 threads x 16 B = 32 lines)
+// BT = workgroup tile (128 or 64).  NW = 4: 2x2 waves, each (BT/2)x(BT/2) outputs = MT x MT MFMA 32x32
+// tiles, MT = BT/64.  NW = 8 (BT = 128): 2x4 waves, each 64x32 outputs = 2 x 1 MFMA tiles: half the
+// accumulators per wave, four waves per SIMD with two workgroups per CU (the shape of the fp64 kernel's
+// large launches, dgemm.hip).
+template <int MODE, int BT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void sgemm_nt_kernel(SGemmArgs g) {
+  constexpr int MT = BT / 64;                          // MFMA tiles per wave, rows
+  constexpr int NTW = (NW == 8) ? 1 : BT / 64;         // MFMA tiles per wave, columns
+  constexpr int WT = BT / 2;                           // rows per wave
+  constexpr int WTN = (NW == 8) ? BT / 4 : BT / 2;     // columns per wave
+  constexpr int NQ = BT * 8 / (NW * 64);               // staging loads per thread per operand
+  constexpr int SROWS = NW * 8;                        // rows one staging pass covers
   __shared__ __attribute__((aligned(16))) float lds[2][2][BT * SGEMM_BK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -122,23 +126,24 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
   // staging: thread -> (row, 16-B chunk); chunk swizzled on the global side
   const int srow = tid >> 3;
   const int schunk = tid & 7;
-  const int gchunk = schunk ^ ((srow >> 1) & 7);  // SROWS*q (multiples of 32) never change the swizzle
+  const int gchunk = schunk ^ ((srow >> 1) & 7);  // SROWS*q (multiples of 32) never change the swizzle: srow < SROWS, and (srow + SROWS * q) >> 1 & 7 == srow >> 1 & 7 for SROWS = 32 or 64
   const float *Ap = Ag + (long)srow * g.lda + gchunk * 4;
   const float *Bp = Bg + (long)srow * g.ldb + gchunk * 4;
   const long a_step = (long)SROWS * g.lda, b_step = (long)SROWS * g.ldb;
 
   // fragments: lane -> row (lane & 31) of its MFMA tile, k-half (lane >> 5)
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = (NW == 8) ? wid >> 2 : wid >> 1;
+  const int wc = (NW == 8) ? wid & 3 : wid & 1;
   const int frow = lane & 31, fh = lane >> 5;
   const int abase = (wr * WT + frow) * SGEMM_BK;
-  const int bbase = (wc * WT + frow) * SGEMM_BK;
+  const int bbase = (wc * WTN + frow) * SGEMM_BK;
   int xc[4];  // LDS float offset of chunk 2c + fh of this lane's row (swizzle depends on frow only:
               // wave / MFMA-tile row offsets are multiples of 32)
 #pragma unroll
   for (int c = 0; c < 4; ++c) xc[c] = ((2 * c + fh) ^ ((frow >> 1) & 7)) << 2;
 
   // C fragment of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  float *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WT;
+  float *Cg = g.C + (long)(ti * BT + wr * WT) * g.ldc + tj * BT + wc * WTN;
   const int coff = (4 * fh) * (int)g.ldc + frow;
   const float alpha = g.alpha;
 
@@ -147,13 +152,13 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
     sload16_to_lds(Ap + q * a_step, &lds[0][0][(wid * 8 + SROWS * q) * SGEMM_BK]);
     sload16_to_lds(Bp + q * b_step, &lds[0][1][(wid * 8 + SROWS * q) * SGEMM_BK]);
   }
-  f32x16 acc[MT][MT];
+  f32x16 acc[MT][NTW];
   if (beta != 0.0f) {
     const float sc = beta / alpha;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < MT; ++n)
+      for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int v = 0; v < 16; ++v)
           acc[m][n][v] = sc * (Cg + (long)(m * 32 + (v & 3) + 8 * (v >> 2)) * g.ldc)[coff + n * 32];
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < MT; ++n)
+      for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.0f;
   }
@@ -184,17 +189,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
     const float *lb = lds[cur][1];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      f32x4 a[MT], b[MT];
+      f32x4 a[MT], b[NTW];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4 *>(la + abase + m * 32 * SGEMM_BK + xc[c]);
 #pragma unroll
-      for (int n = 0; n < MT; ++n) b[n] = *reinterpret_cast<const f32x4 *>(lb + bbase + n * 32 * SGEMM_BK + xc[c]);
+      for (int n = 0; n < NTW; ++n) b[n] = *reinterpret_cast<const f32x4 *>(lb + bbase + n * 32 * SGEMM_BK + xc[c]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < MT; ++n)
+          for (int n = 0; n < NTW; ++n)
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], b[n][j], acc[m][n], 0, 0, 0);
     }
     if (more) swait_vmcnt0();
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_kernel(SGemmArgs g) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < MT; ++n)
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int v = 0; v < 16; ++v)
         (Cg + (long)(m * 32 + (v & 3) + 8 * (v >> 2)) * g.ldc)[coff + n * 32] = alpha * acc[m][n][v];
@@ -306,6 +311,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
     else                                                                                  \
       hipLaunchKernelGGL((__VA_ARGS__), (GRID), (BLOCK), 0, s, g);                         \
   } while (0)
+  const long wave8_min = 3072;  // as in dgemm.hip; the shape matters less here (N = 32768: 314.1 -> 312.5 ms)
   const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
   // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
   if (g.prio == 1 && !small) g.prio = 0;
@@ -317,17 +323,23 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)
-      GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_RECT, 64>);
+      GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_RECT, 64, 4>);
     else
-      GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_LOWER, 64>);
+      GOGP_LAUNCH(dim3(n64), dim3(256), sgemm_nt_kernel<GEMM_LOWER, 64, 4>);
+  } else if (mode == GEMM_LAUUM || ntiles >= wave8_min) {
+    const dim3 gridd(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block8(512);
+    if (mode == GEMM_RECT)
+      GOGP_LAUNCH(gridd, block8, sgemm_nt_kernel<GEMM_RECT, 128, 8>);
+    else if (mode == GEMM_LOWER)
+      GOGP_LAUNCH(gridd, block8, sgemm_nt_kernel<GEMM_LOWER, 128, 8>);
+    else
+      GOGP_LAUNCH(gridd, block8, sgemm_nt_kernel<GEMM_LAUUM, 128, 8>);
   } else {
     const dim3 gridd(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles), block(256);
     if (mode == GEMM_RECT)
-      GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_RECT, 128>);
-    else if (mode == GEMM_LOWER)
-      GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_LOWER, 128>);
+      GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_RECT, 128, 4>);
     else
-      GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_LAUUM, 128>);
+      GOGP_LAUNCH(gridd, block, sgemm_nt_kernel<GEMM_LOWER, 128, 4>);
   }
 #undef GOGP_LAUNCH
 }

@@ -58,6 +58,74 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double *s
   }
 }
 
+// the fp32 twin: v_mfma_f32_32x32x2_f32 (4096 flop, 16 passes), eight independent accumulators
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_f32_peak_kernel(int iters, float *sink, unsigned long long *clk) {
+  f32x16p c0 = {0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+  float a = 1.0f + 1e-6f * threadIdx.x, b = 1.0f - 1e-6f * threadIdx.x;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  int cnt = iters;
+  asm volatile(
+      "1:\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %9, %10, %0\n\t"
+      "v_mfma_f32_32x32x2_f32 %1, %9, %10, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %2, %9, %10, %2\n\t"
+      "v_mfma_f32_32x32x2_f32 %3, %9, %10, %3\n\t"
+      "v_mfma_f32_32x32x2_f32 %4, %9, %10, %4\n\t"
+      "v_mfma_f32_32x32x2_f32 %5, %9, %10, %5\n\t"
+      "v_mfma_f32_32x32x2_f32 %6, %9, %10, %6\n\t"
+      "v_mfma_f32_32x32x2_f32 %7, %9, %10, %7\n\t"
+      "s_sub_u32 %8, %8, 1\n\t"
+      "s_cmp_lg_u32 %8, 0\n\t"
+      "s_cbranch_scc1 1b"
+      : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7), "+s"(cnt)
+      : "v"(a), "v"(b)
+      : "scc");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float s = c0[0] + c1[1] + c2[2] + c3[3] + c4[4] + c5[5] + c6[6] + c7[7];
+  if (s == 12345.678f) sink[0] = s;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
+int mfma_f32_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz) {
+  float *sink = nullptr;
+  unsigned long long *clk = nullptr;
+  if (hipMalloc(&sink, 8) != hipSuccess) return GOGP_EHIP;
+  if (hipMalloc(&clk, 16) != hipSuccess) return GOGP_EHIP;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return GOGP_EHIP;
+  const int blocks = prop.multiProcessorCount * 2;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(mfma_f32_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters / 4 + 1, sink,
+                     (unsigned long long *)nullptr);
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_f32_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink, clk);
+  (void)hipEventRecord(e1, 0);
+  if (hipEventSynchronize(e1) != hipSuccess) return GOGP_EHIP;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 32 * 32 * 2;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  unsigned long long h[2] = {0, 0};
+  (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  if (cyc_per_mfma) *cyc_per_mfma = (double)h[0] / ((double)iters * 8.0 * 2.0);
+  if (clock_mhz) *clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  (void)hipFree(clk);
+  return GOGP_OK;
+}
+
 // tflops: achieved rate with every SIMD issuing; cyc_per_mfma / clock_mhz from wave 0.
 int mfma_f64_peak(int iters, double *tflops, double *cyc_per_mfma, double *clock_mhz) {
   double *sink = nullptr;
@@ -106,6 +174,15 @@ extern "C" int gogp_mfma_f64_peak(int device, int iters, double *tflops, double 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
   return mfma_f64_peak(iters, tflops, cyc_per_mfma, clock_mhz);
+}
+
+extern "C" int gogp_mfma_f32_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                                  double *clock_mhz) {
+  if (!tflops || iters <= 0) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  return mfma_f32_peak(iters, tflops, cyc_per_mfma, clock_mhz);
 }
 
 extern "C" int gogp_test_dgemm_nt(int device, int64_t M, int64_t N, int64_t K, double alpha,
@@ -202,6 +279,39 @@ extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, 
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
+  if (getenv("GOGP_BENCH_GEMM_F32")) {
+    // the fp32 tile kernel on the same buffers read as floats (zero-filled: the values do not matter)
+    (void)hipMemsetAsync(dA, 0, (size_t)M * Kld * sizeof(double), 0);
+    (void)hipMemsetAsync(dB, 0, (size_t)N * Kld * sizeof(double), 0);
+    (void)hipMemsetAsync(dC, 0, (size_t)M * N * sizeof(double), 0);
+    GemmProfile pf32;
+    pf32.on = true;
+    hipEvent_t f0, f1;
+    (void)hipEventCreate(&f0);
+    (void)hipEventCreate(&f1);
+    const float *fA = reinterpret_cast<const float *>(dA), *fB = reinterpret_cast<const float *>(dB);
+    float *fC = reinterpret_cast<float *>(dC);
+    const double beta32 = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
+    for (int w = 0; w < 2; ++w)
+      launch_gemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, fA, Kld, fB, Kld, beta32, fC, N, nullptr, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(f0, 0);
+    for (int r = 0; r < reps; ++r)
+      launch_gemm_nt(0, (GemmMode)mode, mt, nt, Kld, -1e-3, fA, Kld, fB, Kld, beta32, fC, N, &pf32, nullptr);
+    (void)hipEventRecord(f1, 0);
+    hipError_t e32 = hipEventSynchronize(f1);
+    float ms32 = 0.f;
+    (void)hipEventElapsedTime(&ms32, f0, f1);
+    if (ms_per_launch) *ms_per_launch = ms32 / reps;
+    if (tflops) *tflops = pf32.flops / (ms32 * 1e-3) / 1e12;
+    for (auto ev_ : pf32.pool) (void)hipEventDestroy(ev_);
+    (void)hipEventDestroy(f0);
+    (void)hipEventDestroy(f1);
+    (void)hipFree(dA);
+    (void)hipFree(dB);
+    (void)hipFree(dC);
+    return e32 == hipSuccess ? GOGP_OK : GOGP_EHIP;
+  }
   const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
   // GOGP_BENCH_GEMM_LD0=1: every operand row aliases row 0 (lda = ldb = 0): all operand loads hit in the
   // caches -- the kernel's rate with memory latency taken out (diagnostic)

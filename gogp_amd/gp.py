@@ -393,6 +393,15 @@ def mfma_f64_peak(iters: int = 20000, device: int = -1, details: bool = False):
     return (v.value, c.value, m.value) if details else v.value
 
 
+def mfma_f32_peak(iters: int = 20000, device: int = -1, details: bool = False):
+    """The same microbenchmark for the fp32 path's v_mfma_f32_32x32x2_f32."""
+    v, c, m = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = _lib.hooks().gogp_mfma_f32_peak(device, iters, ctypes.byref(v), ctypes.byref(c), ctypes.byref(m))
+    if rc != _lib.GOGP_OK:
+        raise GogpError(rc, "mfma_f32_peak")
+    return (v.value, c.value, m.value) if details else v.value
+
+
 def dgemm_nt_check(A: np.ndarray, B: np.ndarray, C: np.ndarray, alpha=1.0, beta=0.0,
                   device: int = -1) -> np.ndarray:
     """C = beta*C + alpha*A@B.T on the GPU tile kernel (test hook)."""

@@ -336,9 +336,10 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          the exact (fp64, recomputed) Gram matrix                    (default 1)
  *   "cond_limit_log10" 1..300  GOGP_ECOND threshold 10^value -- gonum's package variable
  *                          mat.ConditionTolerance                                   (default 16)
- *   "superpanel_head" 0..8, "head_remaining" >= 0   wider super-panels while more than head_remaining
+ *   "superpanel_head" -1..8, "head_remaining" >= 0   wider super-panels while more than head_remaining
  *                          panels are still to come (the chain has slack there; bulk updates with a longer
- *                          K are more efficient); 0 switches it off                       (default 3, 16)
+ *                          K are more efficient); 0 switches it off; -1: 3, on the fp32 path 4
+ *                                                                                         (default -1, 16)
  *   "kinv_fused"   -1|0|1  K^-1 accumulated behind the triangular inverse as one rank-k update per
  *                          super-panel of Y (1) or formed by one launch over the finished Y in
  *                          gogp_gradient (0); -1: fused up to N = 10240                    (default -1)

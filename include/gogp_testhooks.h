@@ -21,6 +21,9 @@ extern "C" {
  * the shader clock in MHz observed by one wave during the run. */
 int gogp_mfma_f64_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
                        double *clock_mhz);
+/* The same for the fp32 path's instruction, v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s spec). */
+int gogp_mfma_f32_peak(int device, int iters, double *tflops, double *cyc_per_mfma,
+                       double *clock_mhz);
 
 /* Stand-alone fp64 GEMM test hook: C(MxN,row-major) = beta*C + alpha*A(MxK)*B(NxK)^T
  * on host buffers (copied to the device and back); M,N multiples of 128,

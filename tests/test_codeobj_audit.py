@@ -45,7 +45,7 @@ def kernels():
 def test_every_hot_kernel_is_present(kernels):
     names = " ".join(k["name"] for k in kernels)
     for want in ("dgemm_nt_kernel<0, 128, 8>", "dgemm_nt_kernel<1, 128, 8>", "dgemm_nt_kernel<2, 128, 8>",
-                 "sgemm_nt_kernel<1, 128>", "diag256_kernel<true, false, 256>", "gram_kernel<false, double>",
+                 "sgemm_nt_kernel<1, 128, 8>", "sgemm_nt_kernel<1, 128, 4>", "diag256_kernel<true, false, 256>", "gram_kernel<false, double>",
                  "grad_reduce_kernel<32, false, float, true>", "grad_reduce_kernel<0, false, double, true>",
                  "trsv_bwd_kernel<double>", "xgrad_kernel<32>"):
         assert want in names, want
@@ -84,7 +84,7 @@ def test_the_tile_kernels_keep_their_occupancy(kernels):
     kernel and the 4-wave fp64 shape on <= 256 with 64 KB of LDS (two workgroups per CU)."""
     for k in kernels:
         n = k["name"]
-        if re.search(r"dgemm_nt_kernel<\d, 128, 8>", n) or re.search(r"sgemm_nt_kernel<\d, 128>", n):
+        if re.search(r"dgemm_nt_kernel<\d, 128, 8>", n) or re.search(r"sgemm_nt_kernel<\d, 128, \d>", n):
             assert k["vgpr_count"] <= 128, (n, k["vgpr_count"])
             assert k["group_segment_fixed_size"] <= 65536, n
             assert k.get("sgpr_spill_count", 0) == 0, n
