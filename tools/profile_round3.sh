@@ -22,6 +22,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LD
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c5 -- python3 $R/bench.py --config 5 --nobs 16384 --steps 2 --warmup 1 $FAST > $O/pmc_fetch_c5.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_write_c5 -- python3 $R/bench.py --config 5 --nobs 16384 --steps 2 --warmup 1 $FAST > $O/pmc_write_c5.log 2>&1; echo "pmc c5 done"
 cd $R
+{ python3 tools/gemm_bench.py; GOGP_BENCH_GEMM_LD0=1 python3 tools/gemm_bench.py; GOGP_BENCH_GEMM_F32=1 python3 tools/gemm_bench.py; } 2>&1 | grep -v amdgpu.ids > $O/gemm_bench.txt; echo "gemm bench done"
 python3 tools/pmc_summary.py $O/pmc_sq_c3 $O/pmc_fetch_c3 $O/pmc_write_c3 > $O/pmc_summary_c3.txt
 python3 tools/pmc_summary.py $O/pmc_sq_c5 $O/pmc_fetch_c5 $O/pmc_write_c5 > $O/pmc_summary_c5.txt
 python3 tools/roofline_from_profiles.py 16384 dgemm_nt_kernel 78.6 $O/stats_c3 $O/pmc_sq_c3 > $O/roofline_c3.json
