@@ -779,8 +779,11 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipEventRecord(ev(h, EV_KINV), h->sk);
     h->kinv_pending = true;
   }
+  h->ydone_valid = false;
   if (eager) {
     (void)hipEventRecord(ev(h, EV_TRTRI), st);
+    (void)hipEventRecord(ev(h, EV_YDONE), st);  // K^-1 = Y Y^T may start here; alpha = Y z (below) runs beside it
+    h->ydone_valid = true;
     h->trtri_done = true;
     h->trtri_pending = true;
   }
@@ -994,12 +997,16 @@ static int compute_kinv_t(gogp_handle *h) {
     order(h, EV_TRTRI, sp, s);
     h->trtri_done = true;
   } else if (h->trtri_pending) {
-    (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+    // Y final is enough to start; what the inverse's chain stream still does behind it (alpha = Y z, a
+    // bandwidth-bound 0.2 ms at N = 16384) reads Y and writes alpha only
+    (void)hipStreamWaitEvent(s, ev(h, h->ydone_valid ? EV_YDONE : EV_TRTRI), 0);
   }
-  h->trtri_pending = false;
   // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
   launch_gemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, reinterpret_cast<const T *>(h->bufY), ld,
                  reinterpret_cast<const T *>(h->bufY), ld, 0.0, reinterpret_cast<T *>(h->bufA), ld, pf);
+  // whatever follows on s is ordered behind ALL of the inverse's chain stream
+  if (h->trtri_pending && h->ydone_valid) (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+  h->trtri_pending = false;
   h->have_kinv = true;
   return GOGP_OK;
 }

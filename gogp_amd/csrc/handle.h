@@ -95,6 +95,7 @@ struct gogp_handle {
   bool kinv_pending = false;   // K^-1 is being accumulated on sk (wait for EV_KINV)
   bool trtri_done = false;     // Y = L^-T of the current factor is (being) computed
   bool trtri_pending = false;  // ... and still running on st/s2 (wait for EV_TRTRI)
+  bool ydone_valid = false;    // EV_YDONE was recorded by the factorisation trtri_pending refers to
   bool alpha_pending = false;   // alpha was enqueued on sp; consumers on s wait for ev_alpha
   // state
   std::vector<double> theta_s, theta_n;
@@ -163,7 +164,8 @@ static inline int fail(gogp_handle *h, int code, const char *msg) {
 
 // ---- cross-stream events -----------------------------------------------------------------
 enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_KINV = 7,
-       EV_BASE = 8 };
+       EV_YDONE = 8,  // Y is final (EV_TRTRI: everything on the inverse's chain stream is done, alpha = Y z included)
+       EV_BASE = 9 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static inline hipEvent_t ev(gogp_handle *h, size_t i) {

@@ -1,5 +1,5 @@
-"""Shader clock and board power while the config-3 evaluation loop runs (sysfs / hwmon, sampled from a
-second thread): is the evaluation clock- or power-limited?"""
+"""Shader clock and board power while an evaluation loop runs (sysfs / hwmon, sampled from a second
+thread): is the evaluation clock- or power-limited?   usage: python3 tools/clock_probe.py [config] [nobs] [evaluations]"""
 import glob, os, sys, threading, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -22,9 +22,11 @@ cards = sorted(glob.glob(base + "/pp_dpm_sclk"))
 hw = sorted(glob.glob(base + "/hwmon/hwmon*/power1_average")) + sorted(glob.glob(base + "/hwmon/hwmon*/power1_input"))
 fq = sorted(glob.glob(base + "/hwmon/hwmon*/freq1_input"))
 print("sclk files:", cards[:2], "power files:", hw[:2], "freq files:", fq[:2], flush=True)
-wl = configs.workload(int(sys.argv[1]) if len(sys.argv) > 1 else 3, None)
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+wl = configs.workload(cfg, int(sys.argv[2]) if len(sys.argv) > 2 else None)
+NEV = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 X, y = wl.inputs()
-g = G.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0)
+g = G.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, device=0, precision=32 if wl.dtype == "f32" else 64)
 g.Observe(wl.log_theta(0)); g.Gradient()
 samples, stop = [], False
 def sampler():
@@ -38,12 +40,12 @@ def sampler():
 th = threading.Thread(target=sampler); th.start()
 time.sleep(0.3)
 t0 = time.perf_counter()
-for k in range(40):
+for k in range(NEV):
     g.Observe(wl.log_theta(k)); g.Gradient()
 t1 = time.perf_counter()
 time.sleep(0.3)
 stop = True; th.join()
-print("40 evaluations: %.2f ms each" % ((t1 - t0) / 40 * 1e3))
+print("%d evaluations of config %d at N = %d: %.2f ms each" % (NEV, cfg, wl.N, (t1 - t0) / NEV * 1e3))
 idle = [s for s in samples if s[0] < t0 - 0.05]
 busy = [s for s in samples if t0 + 0.5 < s[0] < t1]
 def summ(ss, name):
