@@ -1,3 +1,5 @@
+"""Wall time of Observe and of Gradient at config 3, with the triangular inverse fused into the factorisation
+(eager = 1, default) and deferred to Gradient (eager = 0).   usage: python3 tools/phase_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
