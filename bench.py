@@ -24,7 +24,9 @@ N > 1:
   * configs 1-3 (one evaluation fits and is quoted on ONE GPU): every GPU evaluates its
     own hyperparameter candidate on the full data -- weak scaling, no data-path
     collective; `value` is the replica throughput; ONE evaluation sharded over all ranks
-    is timed as well and reported as `sharded_evaluation`;
+    is timed as well, AFTER that measurement, and reported as `sharded_evaluation` (if it
+    hangs, the line is printed with the extra marked as timed out and the run exits 0: the
+    replica measurement does not depend on it);
   * configs 4-5 (BASELINE quotes them as ONE evaluation over all GPUs): `value` is the
     throughput of the 2-D block-cyclic sharded evaluation (strong scaling).
 
@@ -235,6 +237,26 @@ def launch_ranks(ngpus, argv):
     return subprocess.call(cmd, env=env)
 
 
+def collective_timeout(line, sharded_value, rank, seconds, json_out):
+    """What a rank does when the watchdog over the collective part of an N > 1 run expires; returns the
+    exit code.  Replica configuration with the measurement complete: `value` (independent evaluations, no
+    data-path collective) stands; what hangs is the ADDITIONAL evaluation sharded over all ranks -- rank 0
+    prints the line with the extra marked as timed out, every rank exits 0.  Otherwise (the sharded
+    evaluation IS the value, or nothing was measured yet): rank 0 prints what it has with `error`, exit 3."""
+    if line is not None and not sharded_value:
+        if rank == 0:
+            line["sharded_evaluation"] = {
+                "error": "timed out after %d s (the line's value is the replica measurement, taken before "
+                         "this additional sharded evaluation)" % seconds}
+            print(json.dumps(line), file=json_out, flush=True)
+        return 0
+    if rank == 0:
+        line = line or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
+        line["error"] = "collective timed out after %d s" % seconds
+        print(json.dumps(line), file=json_out, flush=True)
+    return 3
+
+
 class PhaseWatchdog:
     """`with wd.phase("name", seconds):` -- if the block does not finish in time, say which rank is stuck
     in which phase (stderr; rank 0 also prints a JSON line carrying the error) and end the process
@@ -414,11 +436,7 @@ def main():
     wd = None
     if world > 1:
         def _bail():
-            if rank == 0:
-                line = out_holder["line"] or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
-                line["error"] = "collective timed out after %d s" % args.sharded_timeout
-                print(json.dumps(line), file=json_out, flush=True)
-            os._exit(3)
+            os._exit(collective_timeout(out_holder["line"], sharded_value, rank, args.sharded_timeout, json_out))
 
         wd = threading.Timer(args.sharded_timeout, _bail)
         wd.daemon = True

@@ -143,3 +143,25 @@ def test_phase_watchdog_names_rank_and_phase_and_exits_nonzero(tmp_path):
             assert "grouped send/recv ring" in d["error"] and d["value"] is None
         else:
             assert r.stdout.strip() == ""
+
+
+def test_a_hang_in_the_extra_sharded_evaluation_keeps_the_replica_measurement():
+    """N > 1, replica configuration: the line's value is complete before the additional evaluation sharded
+    over all ranks starts; if that one hangs, rank 0 prints the line with the extra marked and every rank
+    exits 0.  When the sharded evaluation IS the value (configs 4, 5), or nothing was measured, exit 3."""
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    buf = io.StringIO()
+    line = {"metric": "m", "value": 27.5, "n_gpus": 2}
+    assert bench.collective_timeout(line, False, 0, 300, buf) == 0
+    d = json.loads(buf.getvalue())
+    assert d["value"] == 27.5 and "timed out after 300 s" in d["sharded_evaluation"]["error"] and "error" not in d
+    buf = io.StringIO()
+    assert bench.collective_timeout({"metric": "m", "value": 27.5}, False, 1, 300, buf) == 0 and buf.getvalue() == ""
+    buf = io.StringIO()
+    assert bench.collective_timeout({"metric": "m", "value": 1.0}, True, 0, 300, buf) == 3
+    assert "collective timed out" in json.loads(buf.getvalue())["error"]
+    buf = io.StringIO()
+    assert bench.collective_timeout(None, False, 0, 300, buf) == 3
+    assert json.loads(buf.getvalue())["value"] is None
