@@ -23,12 +23,15 @@ N=16384, D=8, fp64, one MI355X).
 N > 1:
   * configs 1-3 (one evaluation fits and is quoted on ONE GPU): every GPU evaluates its
     own hyperparameter candidate on the full data -- weak scaling, no data-path
-    collective; `value` is the replica throughput; ONE evaluation sharded over all ranks
-    is timed as well, AFTER that measurement, and reported as `sharded_evaluation` (if it
-    hangs, the line is printed with the extra marked as timed out and the run exits 0: the
-    replica measurement does not depend on it);
+    collective; `value` is the replica throughput.  AFTER that measurement the transport
+    of the sharded evaluation is pre-flighted (communicator, send/recv ring, all-reduce,
+    a first sharded evaluation at N = 64: `preflight`, `rccl_ranks`) and ONE evaluation
+    sharded over all ranks is timed and reported as `sharded_evaluation`; a phase of these
+    that hangs or fails is reported inside the line and the run exits 0 -- the replica
+    measurement does not depend on the library's communicator;
   * configs 4-5 (BASELINE quotes them as ONE evaluation over all GPUs): `value` is the
-    throughput of the 2-D block-cyclic sharded evaluation (strong scaling).
+    throughput of the 2-D block-cyclic sharded evaluation (strong scaling); the pre-flight
+    runs first, each phase under a watchdog that ends the run non-zero with rank and phase.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   "roofline":     the dominant kernel (fp64 MFMA GEMM/SYRK tile kernel), HIP-event
@@ -264,10 +267,24 @@ class PhaseWatchdog:
 
     def __init__(self, rank, json_out, line_holder):
         self.rank, self.json_out, self.line_holder = rank, json_out, line_holder
+        #: replica configuration with the measurement complete (the pre-flight of the sharded transport
+        #: then runs AFTER it): an expiry is reported inside the line (`preflight.error`) and the ranks
+        #: exit 0 -- the replica measurement needs no communicator of the library
+        self.soft = False
 
     def _bail(self, name, seconds):
         msg = "rank %d: phase '%s' did not finish within %d s" % (self.rank, name, seconds)
         print("bench.py: " + msg, file=sys.stderr, flush=True)
+        if self.soft:
+            if self.rank == 0 and self.line_holder.get("line") is not None:
+                line = self.line_holder["line"]
+                line["preflight"] = {"error": msg}
+                line["sharded_evaluation"] = {"error": "not run: the transport's pre-flight did not finish"}
+                try:
+                    print(json.dumps(line), file=self.json_out, flush=True)
+                except Exception:
+                    pass
+            os._exit(0)
         if self.rank == 0:
             line = self.line_holder.get("line") or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
             line["error"] = msg
@@ -380,9 +397,12 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     wl = configs.workload(args.config, args.nobs, args.ndim)
-    # ---- N > 1: pre-flight of the transport the sharded evaluation uses, before anything is timed -----
-    preflight = None
-    if world > 1:
+    # ---- N > 1: pre-flight of the transport the sharded evaluation uses --------------------------------
+    # Where the sharded evaluation IS the value (configs 4, 5) it runs before anything is timed and a phase
+    # that does not finish ends the run non-zero.  In a replica configuration (1-3) the value needs no
+    # communicator of the library: it is measured first, the pre-flight and the additional sharded evaluation
+    # follow, and a failure there is reported inside the line.
+    def run_preflight():
         from gogp_amd.sharded import ShardedGP
         Xp, yp = wl.inputs()
         Xp, yp = Xp[:64], yp[:64]
@@ -400,14 +420,21 @@ def main():
             sgp.Observe(wl.log_theta(0))
             sgp.Gradient()
         nranks_comm, is_rccl = sgp.comm_ranks()
-        preflight = {"comm_ranks": nranks_comm, "rccl": is_rccl, "transport": sgp.transport_text(),
-                     "grid": sgp.grid_text(), "comm_init_s": tp1 - tp0, "ring_s": tp2 - tp1,
-                     "allreduce_s": tp3 - tp2, "first_eval_s": time.perf_counter() - tp3}
-        if nranks_comm != world:
-            print("bench.py: rank %d: the communicator counts %d ranks, the launcher %d" % (rank, nranks_comm, world),
-                  file=sys.stderr, flush=True)
-            os._exit(5)
+        pf = {"comm_ranks": nranks_comm, "rccl": is_rccl, "transport": sgp.transport_text(),
+              "grid": sgp.grid_text(), "comm_init_s": tp1 - tp0, "ring_s": tp2 - tp1,
+              "allreduce_s": tp3 - tp2, "first_eval_s": time.perf_counter() - tp3}
         sgp.close()
+        if nranks_comm != world:
+            raise RuntimeError("the communicator counts %d ranks, the launcher %d" % (nranks_comm, world))
+        return pf
+
+    preflight = None
+    if world > 1 and wl.sharded:
+        try:
+            preflight = run_preflight()
+        except RuntimeError as e:
+            print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+            os._exit(5)
     N, D = wl.N, wl.D
     big = N > 20000
     steps = args.steps if args.steps is not None else (3 if N > 40000 else 5 if big else 10 if N > 6000 else 50)
@@ -734,9 +761,18 @@ def main():
                                                   "GBps": cb / (cross_ms / cross_n * 1e-3) / 1e9}
         out_holder["line"] = out
 
-    # ---- N > 1, replica configs: also time ONE evaluation sharded over all ranks ------------
+    # ---- N > 1, replica configs: the transport's pre-flight, then ONE evaluation sharded over all ranks --
     sharded = None
-    if world > 1 and not sharded_value and not args.no_sharded:
+    if world > 1 and not sharded_value:
+        pw.soft = True
+        try:
+            preflight = run_preflight()
+        except Exception as e:  # noqa: BLE001
+            preflight = {"error": repr(e)[:300]}
+        if out is not None:
+            out["preflight"] = preflight
+            out["rccl_ranks"] = preflight["comm_ranks"] if preflight.get("rccl") else None
+    if world > 1 and not sharded_value and not args.no_sharded and "error" not in preflight:
         try:
             from gogp_amd.sharded import ShardedGP
             sg = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank)

@@ -165,3 +165,30 @@ def test_a_hang_in_the_extra_sharded_evaluation_keeps_the_replica_measurement():
     buf = io.StringIO()
     assert bench.collective_timeout(None, False, 0, 300, buf) == 3
     assert json.loads(buf.getvalue())["value"] is None
+
+
+def test_phase_watchdog_after_a_complete_replica_measurement_reports_inside_the_line(tmp_path):
+    """Replica configuration: the pre-flight of the sharded transport runs AFTER the measurement; a phase
+    that does not return is then reported as `preflight.error` inside the complete line and the ranks exit 0."""
+    script = tmp_path / "wd_soft.py"
+    script.write_text(
+        "import sys, time, json, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "out = os.fdopen(os.dup(1), 'w')\n"
+        "rank = int(sys.argv[1])\n"
+        "holder = {'line': {'metric': 'm', 'value': 27.5} if rank == 0 else None}\n"
+        "wd = bench.PhaseWatchdog(rank, out, holder)\n"
+        "wd.soft = True\n"
+        "with wd.phase('communicator init (unique id broadcast + ncclCommInitRank)', 1):\n"
+        "    time.sleep(30)\n"
+        "print('not reached')\n" % ROOT)
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, str(script), str(rank)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0
+        assert "rank %d" % rank in r.stderr and "communicator init" in r.stderr
+        if rank == 0:
+            d = _one_line(r.stdout)
+            assert d["value"] == 27.5 and "communicator init" in d["preflight"]["error"] and "error" not in d
+        else:
+            assert r.stdout.strip() == ""
