@@ -136,3 +136,23 @@ def test_hook_library_kernels_spill_nothing_either():
 def test_the_product_library_holds_no_diagnostic_kernel(kernels):
     for k in kernels:
         assert "gogp_old" not in k["name"] and "scrub_regs" not in k["name"], k["name"]
+
+
+def test_the_fp64_tile_kernel_reads_its_fragments_with_ds_read_b64():
+    """The XOR swizzle of the operand tiles is conflict-free for ds_read_b64 (two 32-lane groups, 64 banks).
+    hipcc fuses plain `double` loads of two MFMA tiles into ds_read2st64_b64 (four 16-lane groups, 32 banks:
+    2-way conflicts, SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in round 3's first PMC pass), which is
+    why dgemm.hip issues the reads as inline assembly.  Lock it: no fused read in any shape of the kernel."""
+    import agpr_static
+    seen = 0
+    for want in ("dgemm_nt_kernel<0, 128, 8>", "dgemm_nt_kernel<1, 128, 8>", "dgemm_nt_kernel<2, 128, 8>",
+                 "dgemm_nt_kernel<0, 128, 4>", "dgemm_nt_kernel<1, 128, 4>", "dgemm_nt_kernel<0, 64, 4>",
+                 "dgemm_nt_kernel<1, 64, 4>"):
+        name, txt, sym = agpr_static.disassemble(LIB, want)
+        assert name is not None, want
+        ops = [t.split()[0] for _, t, _ in agpr_static.kernel_lines(txt, sym)]
+        assert not [o for o in ops if o.startswith("ds_read2")], (want, set(o for o in ops if o.startswith("ds_")))
+        assert ops.count("ds_read_b64") >= 16, (want, ops.count("ds_read_b64"))
+        assert ops.count("v_mfma_f64_16x16x4_f64") >= 16, want
+        seen += 1
+    assert seen == 7
