@@ -240,14 +240,18 @@ def launch_ranks(ngpus, argv):
     return subprocess.call(cmd, env=env)
 
 
-def collective_timeout(line, sharded_value, rank, seconds, json_out):
+def collective_timeout(line, sharded_value, rank, seconds, json_out, measurement_done=None):
     """What a rank does when the watchdog over the collective part of an N > 1 run expires; returns the
     exit code.  Replica configuration with the measurement complete: `value` (independent evaluations, no
     data-path collective) stands; what hangs is the ADDITIONAL evaluation sharded over all ranks -- rank 0
     prints the line with the extra marked as timed out, every rank exits 0.  Otherwise (the sharded
-    evaluation IS the value, or nothing was measured yet): rank 0 prints what it has with `error`, exit 3."""
-    if line is not None and not sharded_value:
-        if rank == 0:
+    evaluation IS the value, or nothing was measured yet): rank 0 prints what it has with `error`, exit 3.
+    `measurement_done` is state EVERY rank has (set after the replica timing); only rank 0 holds a line, so
+    deciding from `line` alone would make ranks 1.. exit 3 and the launcher tear rank 0 down before it prints."""
+    done = (line is not None) if measurement_done is None else bool(measurement_done)
+    if done and not sharded_value:
+        if rank == 0 and line is not None:
+            line["transport_ok"] = False
             line["sharded_evaluation"] = {
                 "error": "timed out after %d s (the line's value is the replica measurement, taken before "
                          "this additional sharded evaluation)" % seconds}
@@ -279,6 +283,8 @@ class PhaseWatchdog:
             if self.rank == 0 and self.line_holder.get("line") is not None:
                 line = self.line_holder["line"]
                 line["preflight"] = {"error": msg}
+                line["transport_ok"] = False
+                line["rccl_ranks"] = 0
                 line["sharded_evaluation"] = {"error": "not run: the transport's pre-flight did not finish"}
                 try:
                     print(json.dumps(line), file=self.json_out, flush=True)
@@ -288,6 +294,8 @@ class PhaseWatchdog:
         if self.rank == 0:
             line = self.line_holder.get("line") or {"metric": "GP.Observe+Gradient evals/sec", "value": None}
             line["error"] = msg
+            line["transport_ok"] = False
+            line["rccl_ranks"] = 0
             try:
                 print(json.dumps(line), file=self.json_out, flush=True)
             except Exception:
@@ -463,7 +471,8 @@ def main():
     wd = None
     if world > 1:
         def _bail():
-            os._exit(collective_timeout(out_holder["line"], sharded_value, rank, args.sharded_timeout, json_out))
+            os._exit(collective_timeout(out_holder["line"], sharded_value, rank, args.sharded_timeout, json_out,
+                                        measurement_done=out_holder.get("measurement_done", False)))
 
         wd = threading.Timer(args.sharded_timeout, _bail)
         wd.daemon = True
@@ -592,7 +601,12 @@ def main():
                 "parallelism": par_text,
             },
             "lml": lml,
-            "rccl_ranks": (preflight["comm_ranks"] if preflight and preflight["rccl"] else None),
+            # N > 1: did the transport of the sharded evaluation come up (communicator, send/recv ring, all-reduce,
+            # a first sharded evaluation)?  One boolean a driver can read without parsing `preflight`; rccl_ranks is
+            # ncclCommCount, 0 (never null) when RCCL did not carry the run.  N = 1: no transport, both absent.
+            **({"transport_ok": bool(preflight and "error" not in preflight),
+                "rccl_ranks": int(preflight["comm_ranks"]) if preflight and preflight.get("rccl") else 0}
+               if world > 1 else {}),
             "preflight": preflight,
             "roofline": {
                 "bound": "mfma",
@@ -760,6 +774,7 @@ def main():
                 out["produce"]["cross_kernel"] = {"algorithmic_bytes": cb, "ms": cross_ms / cross_n,
                                                   "GBps": cb / (cross_ms / cross_n * 1e-3) / 1e9}
         out_holder["line"] = out
+        out_holder["measurement_done"] = True  # on every rank: the replica value needs nothing collective any more
 
     # ---- N > 1, replica configs: the transport's pre-flight, then ONE evaluation sharded over all ranks --
     sharded = None
@@ -771,7 +786,8 @@ def main():
             preflight = {"error": repr(e)[:300]}
         if out is not None:
             out["preflight"] = preflight
-            out["rccl_ranks"] = preflight["comm_ranks"] if preflight.get("rccl") else None
+            out["transport_ok"] = "error" not in preflight
+            out["rccl_ranks"] = int(preflight["comm_ranks"]) if preflight.get("rccl") else 0
     if world > 1 and not sharded_value and not args.no_sharded and "error" not in preflight:
         try:
             from gogp_amd.sharded import ShardedGP
@@ -823,6 +839,8 @@ def main():
             out["lbfgs_loop"] = lbfgs_sharded
         if sharded is not None:
             out["sharded_evaluation"] = sharded
+            if "error" in sharded and world > 1:
+                out["transport_ok"] = False  # the transport came up but the sharded evaluation over it failed
         if world == 1 and not args.no_cpu_baseline:
             def gpu_fn(Xs, ys, x, Z):
                 if len(ys) == N and g is not None:

@@ -89,8 +89,6 @@ HOOK_SYMBOLS = [
      [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, ctypes.c_int, _dp, _dp]),
     ("gogp_test_diag256", ctypes.c_int,
      [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_uint64), _dp]),
-    ("gogp_test_grad64", ctypes.c_int,
-     [ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int, _dp]),
     ("gogp_test_dgemm_nt", ctypes.c_int,
      [ctypes.c_int, _i64, _i64, _i64, ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
 ]

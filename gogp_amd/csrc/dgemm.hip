@@ -59,6 +59,7 @@ struct GemmArgs {
   int new_row0;  // GEMM_LOWER: tile rows >= new_row0 overwrite C (common.h: GemmGrid); INT_MAX: none
   int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
   int prio;      // chain launch: s_setprio 3 (common.h: GemmGrid)
+  int krag0;     // RECT / LOWER: tile rows ti >= krag0 start at k = (ti - krag0) * BT (common.h: GemmGrid); INT_MAX: none
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   if (MODE == GEMM_LOWER && ti >= g.new_row0) beta = 0.0;
   int kbeg = 0, nkt = g.nkt;
   if (MODE == GEMM_RECT && g.ktri) nkt = min(nkt, (tj + 1) * BT / GEMM_BK);
+  if (MODE != GEMM_LAUUM && ti > g.krag0) {  // the rows of A below krag0 are zero left of their own diagonal tile
+    kbeg = (ti - g.krag0) * BT;
+    nkt -= kbeg / GEMM_BK;
+  }
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
     nkt = (g.kend - kbeg) / GEMM_BK;
@@ -337,6 +342,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.new_row0 = (mode == GEMM_LOWER && grid && grid->new_row0 >= 0) ? grid->new_row0 : 0x7fffffff;
   g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
   g.prio = grid ? grid->prio : 0;
+  g.krag0 = (mode != GEMM_LAUUM && mode != GEMM_TRAP && grid && grid->krag0 >= 0 && !g.ktri) ? grid->krag0 : 0x7fffffff;
   g.bstride = tl_batch.stride;
   const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
@@ -367,6 +373,11 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
       for (int j = 0; j < nt; ++j)
         flops += 2.0 * (double)mt * TILE * TILE * (double)std::min<int64_t>(K, (int64_t)(j + 1) * TILE);
     }
+    if (g.krag0 != 0x7fffffff) {
+      flops = 0;
+      for (int i = 0; i < mt; ++i)
+        flops += 2.0 * (double)nt * TILE * TILE * (double)(K - (int64_t)std::max(0, i - g.krag0) * TILE);
+    }
     if (g.rule) {  // count the tiles the filter keeps
       const int tpb = 1 << g.tpb_shift;
       long kept = 0;
@@ -379,7 +390,11 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     }
   } else {
     ntiles = mt * (mt + 1) / 2;
-    if (mode == GEMM_LOWER) {
+    if (mode == GEMM_LOWER && g.krag0 != 0x7fffffff) {
+      flops = 0;
+      for (int i = 0; i < mt; ++i)
+        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - (int64_t)std::max(0, i - g.krag0) * TILE);
+    } else if (mode == GEMM_LOWER) {
       flops = 2.0 * (double)ntiles * TILE * TILE * (double)K;
     } else {
       flops = 0;
@@ -425,6 +440,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     g.nt = nt * 2;
     g.tpb_shift += 1;  // distribution blocks counted in 64-wide tiles
     if (g.new_row0 != 0x7fffffff) g.new_row0 *= 2;
+    if (g.krag0 != 0x7fffffff) g.krag0 *= 2;  // counted in 64-wide tiles (and 64-column steps of the K start)
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
     if (mode == GEMM_RECT)

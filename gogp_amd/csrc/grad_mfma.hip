@@ -15,8 +15,9 @@
 // (R_i, C_j: row / column sums of the tile of G).  Per 64x64 tile of K^-1 the kernel forms S = Xs_r Xs_c^T
 // (64 x 64 x D) and P = G Xs_c (64 x D x 64) with v_mfma_f64_16x16x4_f64 from LDS; what is left per pair on
 // the vector ALU is the kernel function itself (one exp) and a handful of multiplies.  All sums are fp64 and
-// fixed-order (bitwise reproducible).  The x^2 + y^2 - 2xy forms lose nothing that matters here: inputs are
-// O(1), so r^2 carries an absolute error of a few 1e-16, and the components are sums of terms of one sign.
+// fixed-order (bitwise reproducible).  The x^2 + y^2 - 2xy forms cancel relative to |xs|^2, so every tile works on
+// coordinates centred on its first column point (the kernel is translation invariant): what is squared is then of
+// the size of the pair distances, whatever offset the caller's inputs carry (test_ard_gradient_offset_inputs).
 #include "kern_eval.h"
 
 namespace gogp {
@@ -32,7 +33,7 @@ __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) {
 // DP: D rounded up to a multiple of 16 (16, 32, 48, 64); LDS rows have DP + 2 doubles (the MFMA fragment
 // reads of 16 rows x 2 k then hit 64 distinct banks).
 template <int DP, bool LOCAL, class KT>
-__global__ __launch_bounds__(256) void grad_ard_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void grad_ard_mfma_kernel(
     const DevParams *__restrict__ Pp, const double *__restrict__ X, const double *__restrict__ alpha,
     const KT *__restrict__ Kinv, long ld, long n, int nt, int ntiles, double *__restrict__ partials, int ntc,
     BlockMap map, long bstride) {
@@ -88,11 +89,17 @@ __global__ __launch_bounds__(256) void grad_ard_mfma_kernel(
     }
     __syncthreads();  // the previous tile's readers are done
     // ---- scaled coordinates of the tile's rows and columns (zero beyond D and beyond n) ----------------
+    // Centred on the tile's first column point: r^2 = |a|^2 + |b|^2 - 2 a.b and the x^2 R + x^2 C - 2 x (G X) sums
+    // cancel with a relative error of eps |xs|^2 / u^2, harmless for coordinates of the size of the pair distances
+    // but not for uncentred inputs (timestamps: |x / l| ~ 1e5 would leave 1e-6).  The kernel only depends on
+    // differences, so the shift is free; x - ref is exact or rounded relative to the DIFFERENCE.
+    const long cref = (c0 < n ? c0 : n - 1) * D;
     for (int idx = tid; idx < 64 * DP; idx += 256) {
       const int r = idx / DP, d = idx - r * DP;
       const double il = d < D ? P.inv_len[0][d] : 0.0;
-      Xr[r * XS + d] = (d < D && r0 + r < n) ? X[(r0 + r) * D + d] * il : 0.0;
-      Xc[r * XS + d] = (d < D && c0 + r < n) ? X[(c0 + r) * D + d] * il : 0.0;
+      const double ref = d < D ? X[cref + d] : 0.0;
+      Xr[r * XS + d] = (d < D && r0 + r < n) ? (X[(r0 + r) * D + d] - ref) * il : 0.0;
+      Xc[r * XS + d] = (d < D && c0 + r < n) ? (X[(c0 + r) * D + d] - ref) * il : 0.0;
     }
     if (tid < 64) ai[tid] = (r0 + tid < n) ? alpha[r0 + tid] : 0.0;
     else if (tid < 128) aj[tid - 64] = (c0 + tid - 64 < n) ? alpha[c0 + tid - 64] : 0.0;

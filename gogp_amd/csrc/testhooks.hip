@@ -312,7 +312,8 @@ extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, 
     (void)hipFree(dC);
     return e32 == hipSuccess ? GOGP_OK : GOGP_EHIP;
   }
-  const double beta = (mode == GEMM_LAUUM) ? 0.0 : 1.0;
+  // GOGP_BENCH_GEMM_BETA0=1: beta = 0, i.e. no C-tile read (what the C preload costs a tile)
+  const double beta = (mode == GEMM_LAUUM || getenv("GOGP_BENCH_GEMM_BETA0")) ? 0.0 : 1.0;
   // GOGP_BENCH_GEMM_LD0=1: every operand row aliases row 0 (lda = ldb = 0): all operand loads hit in the
   // caches -- the kernel's rate with memory latency taken out (diagnostic)
   const int64_t ld = getenv("GOGP_BENCH_GEMM_LD0") ? 0 : Kld;

@@ -157,8 +157,12 @@ def test_a_hang_in_the_extra_sharded_evaluation_keeps_the_replica_measurement():
     assert bench.collective_timeout(line, False, 0, 300, buf) == 0
     d = json.loads(buf.getvalue())
     assert d["value"] == 27.5 and "timed out after 300 s" in d["sharded_evaluation"]["error"] and "error" not in d
+    assert d["transport_ok"] is False
     buf = io.StringIO()
-    assert bench.collective_timeout({"metric": "m", "value": 27.5}, False, 1, 300, buf) == 0 and buf.getvalue() == ""
+    # ranks != 0 never hold a line (main() sets it on rank 0 only): what they know is that the replica timing is done
+    assert bench.collective_timeout(None, False, 1, 300, buf, measurement_done=True) == 0 and buf.getvalue() == ""
+    assert bench.collective_timeout(None, False, 1, 300, buf, measurement_done=False) == 3 and buf.getvalue() == ""
+    assert bench.collective_timeout(None, True, 1, 300, buf, measurement_done=True) == 3 and buf.getvalue() == ""
     buf = io.StringIO()
     assert bench.collective_timeout({"metric": "m", "value": 1.0}, True, 0, 300, buf) == 3
     assert "collective timed out" in json.loads(buf.getvalue())["error"]
@@ -190,5 +194,6 @@ def test_phase_watchdog_after_a_complete_replica_measurement_reports_inside_the_
         if rank == 0:
             d = _one_line(r.stdout)
             assert d["value"] == 27.5 and "communicator init" in d["preflight"]["error"] and "error" not in d
+            assert d["transport_ok"] is False and d["rccl_ranks"] == 0  # never null: a driver reads one boolean
         else:
             assert r.stdout.strip() == ""

@@ -7,7 +7,8 @@ metadata of every kernel in libgogp_hip.so (tools/codeobj_audit.py: .hip_fatbin 
 -> `llvm-readelf --notes`) and pins:
 
   * no VGPR spills anywhere (vgpr_spill_count == 0): neither scratch nor AGPR spill copies;
-  * no AGPRs except as MFMA accumulators of an allow-listed kernel (the tile kernels use none: their
+  * no AGPRs at all (round 4: the allow-list is empty -- grad_ard_mfma_kernel, the one kernel that used them,
+    is held to 2 workgroups per CU and stays inside the architectural registers; the tile kernels use none: their
     accumulators are VGPRs);
   * at most 256 VGPRs per kernel (so that two waves fit on a SIMD);
   * no private (scratch) segment;
@@ -116,21 +117,15 @@ def test_the_config5_gradient_instance_is_lean(kernels):
 
 
 def test_hook_library_kernels_spill_nothing_either():
+    """The default hook library holds measurement hooks only.  The forensic probe of the gradient instances round 2
+    removed (the pre-round-2 source in namespace gogp_old, the 64-accumulator instance rebuilt from today's template,
+    the register scrub kernel: all over the limits on purpose) lives in libgogp_probe.so, built by `make probe` alone
+    (tools/exp/, tools/agpr_probe.py) -- it is in no default build and ships with no test."""
     if not os.path.exists(HOOKS):
         pytest.skip("libgogp_testhooks.so not built")
-    # diagnostic kernels are over the limits on purpose (gogp_test_grad64, tools/agpr_probe.py): the whole
-    # pre-round-2 gradient source in namespace gogp_old (its sharded 64-accumulator instance is the one round 2
-    # removed from the product for wrong sums), that instance rebuilt from today's template, and the register
-    # scrub kernel that owns the whole register file of its SIMD lane
-    on_purpose = ("gogp_old::", "grad_reduce_kernel<64, true, double, false>", "scrub_regs_kernel")
-    seen = set()
     for k in codeobj_audit.kernels(HOOKS):
-        hit = [n for n in on_purpose if n in k["name"]]
-        if hit:
-            seen.add(hit[0])
-            continue
+        assert "gogp_old" not in k["name"] and "scrub_regs" not in k["name"], k["name"]
         assert k.get("vgpr_spill_count", 0) == 0 and k["vgpr_count"] <= 256, k["name"]
-    assert seen == set(on_purpose)
 
 
 def test_the_product_library_holds_no_diagnostic_kernel(kernels):

@@ -316,6 +316,35 @@ def test_ard_gradient_many_dimensions(gpmod, D, n, kind):
     g.close()
 
 
+@pytest.mark.parametrize("D,n", [(3, 900), (20, 1500)])
+def test_ard_gradient_offset_inputs(gpmod, D, n):
+    """Uncentred inputs (timestamps): every coordinate carries an offset of 1e6 length scales.  The reference and
+    the oracle work on per-pair differences; the matrix-core reduction (grad_mfma.hip) expands r^2 = |a|^2 + |b|^2
+    - 2 a.b and must therefore centre each tile first -- uncentred it loses eps * |x/l|^2 / u^2 ~ 1e-4.  The same
+    problem without the offset is the reference value (the kernel is translation invariant)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(4242 + D)
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise
+    ell = np.sqrt(D / 6.0) * (1 + np.arange(D) / (2.0 * D))
+    x = np.log(np.concatenate([[1.1], ell, [0.2]]))
+    # power-of-two offsets keep X + off - off == X bit for bit where |X| < 1: both problems hold the SAME points
+    off = 2.0 ** 20 * np.ones(D)
+    assert off.min() / ell.max() > 2e5
+    Xo = X + off
+    X0 = Xo - off  # what survives the offset's rounding: the points the shifted problem really contains
+    o = FastOracle(D, simil, noise)
+    o.set_data(X0, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    g = gpmod.GP(D, simil, noise, X=Xo, Y=y)
+    assert abs(g.Observe(x) - lml_o) <= 1e-9 * abs(lml_o)
+    assert np.abs(g.Gradient() - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
+    g.set_option("ard_mfma_min_dims", 65)  # scalar-row kernel of grad.hip: per-pair differences, no expansion
+    g.Observe(x)
+    assert np.abs(g.Gradient() - grad_o).max() <= 1e-7 * max(1.0, np.abs(grad_o).max())
+    g.close()
+
+
 def test_full_form_gradient_mid_size(gpmod):
     """Input/output gradient at a size that spans several 64-row tiles and 256-panels,
     against central differences of the HIP LML itself on a few coordinates."""

@@ -31,6 +31,7 @@ SGPR_SPILL_ALLOW = {
     # private segment for the callee-saved VGPRs; the spilled SGPRs are hoisted LDS offsets of the unrolled
     # 16-column steps
     r"diag256_kernel<true, false, \d+>": 480,
+    r"diag256_wait_kernel<\d+>": 480,  # the same body behind the input-flag poll (option diag_early)
     # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor
     r"diag256_kernel<false, false, \d+>": 260,
     # multi-term / periodic kernels keep the per-pair loop: kind, scale, period and length tables of up to
@@ -40,10 +41,10 @@ SGPR_SPILL_ALLOW = {
     # hundred in the reference; 32 per-dimension accumulators
     r"xgrad_kernel<32>": 100,
 }
-#: kernels that may use AGPRs: MFMA accumulators the compiler keeps there (written by MFMA under the full
-#: EXEC mask and recomputed per tile -- never a parking place for values that live across divergent
-#: trips, which is what the removed gradient instances' spill copies were: DESIGN.md section 4)
-AGPR_ALLOW = {r"grad_ard_mfma_kernel<\d+, (true|false), (double|float)>": 64}
+#: kernels that may use AGPRs: none.  (Round 3 allowed grad_ard_mfma_kernel 64 of them "as MFMA accumulators"; with
+#: __launch_bounds__(256, 2) the compiler keeps every instance inside 226 architectural VGPRs and uses no AGPR at
+#: all, so the one class of register the removed gradient instances went wrong through is simply absent.)
+AGPR_ALLOW = {}
 
 
 def sgpr_spill_limit(name):

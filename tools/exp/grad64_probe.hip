@@ -1,4 +1,4 @@
-// grad64_th.hip -- diagnostic build for the hook library only (include/gogp_testhooks.h: gogp_test_grad64).
+// grad64_probe.hip -- forensic probe, built only by `make probe` into libgogp_probe.so (tools/exp/gogp_probe.h: gogp_test_grad64).
 //
 // Rounds 1-2 shipped 32- and 64-accumulator instances of the per-pair gradient reduction; the 64-accumulator
 // LOCAL one returned wrong, run-to-run varying sums as soon as a workgroup walked a second tile, and round 2
@@ -8,14 +8,14 @@
 // is, then again after a scrub kernel has filled every VGPR and AGPR of every SIMD with a known pattern.  If
 // the sums follow the pattern, the kernel consumes stale register contents.
 #define GOGP_GRAD_KERNEL_ONLY
-#include "grad.hip"
+#include "../../gogp_amd/csrc/grad.hip"
 
 #include <math.h>
 #include <string.h>
 
 #include <vector>
 
-#include "../../include/gogp_testhooks.h"
+#include "gogp_probe.h"
 
 namespace gogp {
 

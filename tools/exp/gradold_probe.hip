@@ -1,9 +1,9 @@
-// gradold_th.hip -- hook library only: the gradient reduction EXACTLY as it was before round 2 removed its
+// gradold_probe.hip -- probe library only (`make probe`): the gradient reduction EXACTLY as it was before round 2 removed its
 // 32- and 64-accumulator instances (tools/exp/gradold/ = `git show e342069^:gogp_amd/csrc/{grad.hip,common.h,
 // kern_eval.h}`, verbatim), compiled into its own namespace so that the faulty instance
 // grad_reduce_kernel<64, true, double> can be run against today's kernels (gogp_test_grad64, variant 1).
 #define gogp gogp_old
-#include "../../tools/exp/gradold/grad.hip"
+#include "gradold/grad.hip"
 #undef gogp
 
 extern "C" void gogp_old_grad_reduce_local(hipStream_t s, const void *devparams, int ndim, int ard_dims, const double *X,
