@@ -24,7 +24,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <chrono>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -97,10 +96,6 @@ static void free_n_buffers(gogp_handle *h) {
   (void)hipFree(h->rz);
   (void)hipFree(h->rd);
   (void)hipFree(h->rpart);
-  (void)hipFree(h->TX);
-  (void)hipFree(h->Tmt);
-  h->TX = h->Tmt = nullptr;
-  h->cap_tinv = 0;
   h->rw = h->rz = h->rd = h->rpart = nullptr;
   h->dX = h->dy = h->bufA = h->bufL = h->bufY = h->Dinv = nullptr;
   h->z = h->w = h->alpha = h->gpart = nullptr;
@@ -148,7 +143,7 @@ static void free_m_buffers(gogp_handle *h) {
 struct StreamSet {
   int device = -1;
   bool in_use = false;
-  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr, sk = nullptr, sf = nullptr, sq = nullptr;
+  hipStream_t s = nullptr, s2 = nullptr, sp = nullptr, st = nullptr, sl = nullptr, sk = nullptr;
   hipStream_t sg = nullptr;  // capture / replay stream of the candidates' hipGraph, created on first use
   hipStream_t s2_low = nullptr, st_low = nullptr;  // option "inv_prio": low-priority twins, created on first use
 };
@@ -173,10 +168,6 @@ static hipError_t create_stream_set(StreamSet *ss, int device) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sl, hipStreamNonBlocking, normal);
     // K^-1 accumulates behind everything else: whatever the chains leave idle
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sk, hipStreamNonBlocking, least);
-    // the full-height steps of a super-panel gate its bulk update: with the chain
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sf, hipStreamNonBlocking, greatest);
-    // the early-dispatched diagonal blocks: part of the chain
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ss->sq, hipStreamNonBlocking, greatest);
   }
   return e;
 }
@@ -193,7 +184,7 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
     ss = new StreamSet();
     const hipError_t e = create_stream_set(ss, device);
     if (e != hipSuccess) {  // partial sets are not pooled
-      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl, ss->sk, ss->sf, ss->sq})
+      for (hipStream_t q : {ss->s, ss->s2, ss->sp, ss->st, ss->sl, ss->sk})
         if (q) (void)hipStreamDestroy(q);
       delete ss;
       return e;
@@ -208,8 +199,6 @@ static hipError_t acquire_streams(gogp_handle *h, int device) {
   h->st = ss->st;
   h->sl = ss->sl;
   h->sk = ss->sk;
-  h->sf = ss->sf;
-  h->sq = ss->sq;
   return hipSuccess;
 }
 
@@ -247,7 +236,7 @@ static void release_streams(gogp_handle *h) {
   if (h->stream_set) static_cast<StreamSet *>(h->stream_set)->in_use = false;
   h->stream_set = nullptr;
   h->sg = nullptr;
-  h->s = h->s2 = h->sp = h->st = h->sl = h->sk = h->sf = h->sq = nullptr;
+  h->s = h->s2 = h->sp = h->st = h->sl = h->sk = nullptr;
 }
 
 extern "C" void gogp_destroy(gogp_handle *h) {
@@ -261,7 +250,6 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   (void)hipFree(h->scalars);
   (void)hipFree(h->dscr);
   (void)hipFree(h->info);
-  (void)hipFree(h->dflag);
   (void)hipFree(h->gout);
   (void)hipFree(h->devP);
   if (h->hostP) (void)hipHostFree(h->hostP);
@@ -313,8 +301,6 @@ extern "C" int gogp_create(const gogp_desc *desc, int device, gogp_handle **out)
   if (e == hipSuccess) e = hipMalloc(&h->scalars, 8 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->dscr, (size_t)3 * PANEL * PANEL * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->info, sizeof(long long));
-  if (e == hipSuccess) e = hipMalloc(&h->dflag, sizeof(long long));
-  if (e == hipSuccess) e = hipMemset(h->dflag, 0, sizeof(long long));
   if (e == hipSuccess) e = hipMalloc(&h->gout, NACC * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->devP, sizeof(DevParams));
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->hostP, sizeof(DevParams), hipHostMallocDefault);
@@ -487,11 +473,6 @@ static FactorResult judge_scalars(const gogp_handle *h, const double *hs, bool f
   long long info = 0;
   memcpy(&info, hs + 8, sizeof info);
   char buf[160];
-  if (info < 0) {  // an early-dispatched diagonal block never saw its input flag (diag256.hip): a scheduling failure
-    r.rc = GOGP_EHIP;
-    r.msg = "diagonal block dispatched ahead of its input timed out waiting for it (option diag_early)";
-    return r;
-  }
   if (info != 0) {
     r.rc = GOGP_ENOTPD;
     r.notpd = (int64_t)info - 1;
@@ -557,29 +538,6 @@ static void diag_inv_only(gogp_handle *h, hipStream_t s, const float *L, int64_t
   launch_convert_block(s, D64, PANEL, Dp, PANEL, PANEL, PANEL);
 }
 
-// The diagonal block of panel p on the chain stream sp.  Option "diag_early" (fp64): the kernel goes to stream sq
-// WITHOUT waiting for its input, takes a CU while the previous panel is still being solved and updated, and polls
-// the flag raised here, on sp, behind everything that produces the block; sp continues when the block is done.
-static inline bool diag_early_on(const gogp_handle *h, hipStream_t sp) {
-  if (h->prec != 64 || !h->lookahead || !h->dflag || h->sq == sp || h->sq == h->s) return false;
-  return h->diag_early < 0 ? h->npad >= 2048 : h->diag_early != 0;
-}
-static void chain_diag(gogp_handle *h, hipStream_t sp, const double *A, int64_t ld, double *L, int64_t ldl, double *Dp,
-                       int64_t c0) {
-  if (!diag_early_on(h, sp)) {
-    diag_block(h, sp, A, ld, L, ldl, Dp, c0);
-    return;
-  }
-  const long long v = ++h->flag_seq;
-  launch_flag_raise(sp, h->dflag, v);
-  launch_diag256_wait(h->sq, A, ld, L, ldl, Dp, c0, h->n, h->info, h->dflag, v);
-  order(h, EV_DIAG, h->sq, sp);
-}
-static void chain_diag(gogp_handle *h, hipStream_t sp, const float *A, int64_t ld, float *L, int64_t ldl, float *Dp,
-                       int64_t c0) {
-  diag_block(h, sp, A, ld, L, ldl, Dp, c0);
-}
-
 // Width (in 256-panels) of the super-panel that starts at panel P0: `superpanel`, or -- option
 // "superpanel_head" -- a wider one while more than `head_remaining` panels are still to come: the bulk
 // updates of the first part of the sweep then carry K = 256 * superpanel_head (fewer passes over the
@@ -604,163 +562,6 @@ static inline int superpanel_width(const gogp_handle *h, int npanel, int P0) {
   return (npanel - P0 < sw) ? npanel - P0 : sw;
 }
 
-// ---- super-panel schedule (option "sched" = 1) --------------------------------------------------------------------
-// Rounds 1-3 ran, per 256-wide panel, diagonal block -> panel solve over ALL rows below -> update inside the
-// super-panel over all rows -> ... on the chain stream: nine dependent full-height launches per super-panel of three
-// panels, each of which needs ~190 us just to find workgroup slots next to the bulk updates (kernel trace, round 4:
-// a 720-workgroup K = 256 panel solve holds 6 TFLOP/s there), so that the chain was busy 42 of the sweep's 47 ms and
-// chain and bulk took turns waiting for each other.  Here the chain only factors the W x W diagonal block
-// T = L[C0:CE, C0:CE] (W = 256 * panels: the same diag256 / solve / update steps on at most W rows) and assembles
-// T^-1 from the 256-block inverses; everything full-height is then ONE product with T^-T per super-panel,
-//     L[CE:, C0:CE] = A[CE:, C0:CE] T^-T          (the same flops as the panel-by-panel substitution: ktri)
-//     Y[0:C0, C0:CE] = R[0:C0, C0:CE] T^-T,  Y[C0:CE, C0:CE] = T^-T       (triangular inverse)
-// split into a head (the next super-panel's rows, on the chain: the next diagonal block waits for nothing else) and
-// the rest (stream sf, beside the previous bulk update).
-// widest super-panel (in 256-panels) the options allow = leading dimension of the T^-1 store
-constexpr int TMT_BLOCKS = 8;  // scratch blocks M of one block diagonal (super-panels are at most 8 panels wide)
-static inline int tinv_panels(const gogp_handle *h) {
-  const int head = h->superpanel_head < 0 ? (h->prec == 32 ? 4 : 3) : h->superpanel_head;
-  return std::max(h->superpanel, head);
-}
-static int ensure_tinv(gogp_handle *h) {
-  if (h->batch_mode) return GOGP_OK;  // the candidates' arena carries its own (cand_layout)
-  const int64_t tld = (int64_t)tinv_panels(h) * PANEL;
-  const size_t need = (size_t)std::max(h->npad, h->cap_npad) * (size_t)tld;
-  if (!h->TX || h->cap_tinv < need) {
-    (void)hipFree(h->TX);
-    (void)hipFree(h->Tmt);
-    h->TX = h->Tmt = nullptr;
-    h->cap_tinv = 0;
-    HIPCHK(h, hipMalloc(&h->TX, need * h->esz()));
-    HIPCHK(h, hipMalloc(&h->Tmt, (size_t)TMT_BLOCKS * PANEL * PANEL * h->esz()));
-    h->cap_tinv = need;
-  }
-  h->tinv_ld = tld;  // every block that is read is written in the same sweep: a new ld needs no clearing
-  return GOGP_OK;
-}
-
-// X = T^-1 (lower, row-major, ld tinv_ld) of the super-panel starting at panel P0, from its 256-block inverses and the
-// factor's blocks inside it:  X_ii = Dinv_i,  X_ij = -Dinv_i sum_{k=j}^{i-1} L_ik X_kj  (i > j), block diagonal by
-// block diagonal: all blocks at distance d = i - j in two launches of the batched 256-block product (solve.hip:
-// blockmm_kernel: M = L[i, j..i-1] X[j..i-1, j], then X_ij = -Dinv_i M) -- 1 + 2 (panels - 1) launches on the chain.
-template <class T>
-static void assemble_tinv(gogp_handle *h, hipStream_t sp, int P0, int nsub) {
-  const int64_t ld = h->npad, tld = h->tinv_ld, C0 = (int64_t)P0 * PANEL;
-  T *X = reinterpret_cast<T *>(h->TX) + C0 * tld;
-  T *MT = reinterpret_cast<T *>(h->Tmt);
-  const T *L = reinterpret_cast<const T *>(h->bufL);
-  const T *Dinv = reinterpret_cast<const T *>(h->Dinv) + (size_t)P0 * PANEL * PANEL;
-  launch_tinv_init(sp, Dinv, X, (T *)nullptr, nsub, tld);
-  for (int d = 1; d < nsub; ++d) {
-    const int cnt = nsub - d;  // blocks (i, i - d), i = d .. nsub-1
-    for (int b0 = 0; b0 < cnt; b0 += 6) {
-      const int nb = std::min(6, cnt - b0);
-      const T *A1[6], *B1[6], *A2[6], *B2[6];
-      T *C1[6], *C2[6];
-      int64_t lda1[6], ldb1[6], ldc1[6], lda2[6], ldb2[6], ldc2[6];
-      int K1[6], K2[6];
-      for (int b = 0; b < nb; ++b) {
-        const int i = d + b0 + b, j = i - d;
-        A1[b] = L + (C0 + (int64_t)i * PANEL) * ld + C0 + (int64_t)j * PANEL;
-        lda1[b] = ld;
-        B1[b] = X + (int64_t)j * PANEL * tld + (int64_t)j * PANEL;
-        ldb1[b] = tld;
-        C1[b] = MT + (size_t)(b0 + b) * PANEL * PANEL;
-        ldc1[b] = PANEL;
-        K1[b] = d * PANEL;
-        A2[b] = Dinv + (size_t)i * PANEL * PANEL;
-        lda2[b] = PANEL;
-        B2[b] = C1[b];
-        ldb2[b] = PANEL;
-        C2[b] = X + (int64_t)i * PANEL * tld + (int64_t)j * PANEL;
-        ldc2[b] = tld;
-        K2[b] = PANEL;
-      }
-      launch_blockmm(sp, nb, A1, lda1, B1, ldb1, C1, ldc1, K1, 1.0);
-      launch_blockmm(sp, nb, A2, lda2, B2, ldb2, C2, ldc2, K2, -1.0);
-    }
-  }
-}
-
-// One super-panel of the Cholesky sweep in the super-panel schedule.  Streams: sp chain (diagonal block, T^-1, head),
-// sf full-height part, s bulk update.  Events (handle.h): +4 T^-1, +5 head, +6 L below the head, +7 next columns
-// below the head, +0 every row of the panels, +1 bulk.
-template <class T>
-static void chol_superpanel(gogp_handle *h, int P0, int nsub, int prevP0, int next_nsub, hipStream_t sp, hipStream_t sf,
-                            hipStream_t s) {
-  const int64_t npad = h->npad, ld = npad, tld = h->tinv_ld;
-  T *A = reinterpret_cast<T *>(h->bufA), *L = reinterpret_cast<T *>(h->bufL);
-  T *Dinv = reinterpret_cast<T *>(h->Dinv);
-  GemmProfile *pf = &h->prof;
-  const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL, W = CE - C0;
-  const int64_t CF = CE + (int64_t)next_nsub * PANEL;
-  const size_t E = EV_BASE + EV_PER * (size_t)P0, Eprev = EV_BASE + EV_PER * (size_t)(prevP0 < 0 ? 0 : prevP0);
-  // ---- chain: the W x W diagonal block, panel by panel on its own rows only ----------------------------------------
-  for (int q = 0; q < nsub; ++q) {
-    const int p = P0 + q;
-    const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
-    T *Dp = Dinv + (size_t)p * PANEL * PANEL;
-    chain_diag(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
-    if (c2 < CE) {
-      GemmGrid gtri;
-      gtri.ktri = h->ktri;
-      gtri.prio = chain_prio_of(h);
-      launch_gemm_nt(sp, GEMM_RECT, (int)((CE - c2) / TILE), 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
-                     L + c2 * ld + c0, ld, pf, &gtri);
-      const int done = q + 1, grp = done & -done;  // binary grouping of the updates inside the block (see sched 0)
-      const int64_t k0 = c2 - (int64_t)grp * PANEL;
-      const int64_t ce = (c2 + (int64_t)grp * PANEL < CE) ? c2 + (int64_t)grp * PANEL : CE;
-      GemmGrid gch;
-      gch.prio = chain_prio_of(h);
-      launch_gemm_nt(sp, GEMM_TRAP, (int)((CE - c2) / TILE), (int)((ce - c2) / TILE), (int64_t)grp * PANEL, -1.0,
-                     L + c2 * ld + k0, ld, L + c2 * ld + k0, ld, 1.0, A + c2 * ld + c2, ld, pf, &gch);
-    }
-  }
-  assemble_tinv<T>(h, sp, P0, nsub);
-  (void)hipEventRecord(ev(h, E + 4), sp);
-  const T *X = reinterpret_cast<const T *>(h->TX) + C0 * tld;
-  if (CF == CE) {  // last super-panel: nothing below
-    (void)hipEventRecord(ev(h, E + 0), sp);
-    return;
-  }
-  const int ntn = (int)((CF - CE) / TILE), mtT = (int)((npad - CF) / TILE), wt = (int)(W / TILE);
-  GemmGrid gtri, gch;
-  gtri.ktri = h->ktri;
-  gtri.prio = gch.prio = chain_prio_of(h);
-  // ---- head (chain): the next super-panel's rows.  A[CE:CF, C0:CE] got its last update from the previous
-  // super-panel's next-columns update below the head (sf)
-  if (prevP0 >= 0 && sp != sf) (void)hipStreamWaitEvent(sp, ev(h, Eprev + 7), 0);
-  launch_gemm_nt(sp, GEMM_RECT, ntn, wt, W, 1.0, A + CE * ld + C0, ld, X, tld, 0.0, L + CE * ld + C0, ld, pf, &gtri);
-  // ... and the next diagonal block's own update (each 256-column from its diagonal block down: the blocks above
-  // belong to R of the fused triangular inverse); last written by the previous bulk update / the Gram build
-  (void)hipStreamWaitEvent(sp, ev(h, prevP0 >= 0 ? Eprev + 1 : (size_t)EV_GRAM), 0);
-  launch_gemm_nt(sp, GEMM_TRAP, ntn, ntn, W, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld, 1.0, A + CE * ld + CE, ld,
-                 pf, &gch);
-  (void)hipEventRecord(ev(h, E + 5), sp);
-  // ---- full-height part (sf): L below the head, then the next super-panel's columns below the head ---------------
-  if (sf != sp) (void)hipStreamWaitEvent(sf, ev(h, E + 4), 0);
-  GemmGrid gtall;
-  gtall.ktri = h->ktri;
-  if (mtT > 0)
-    launch_gemm_nt(sf, GEMM_RECT, mtT, wt, W, 1.0, A + CF * ld + C0, ld, X, tld, 0.0, L + CF * ld + C0, ld, pf, &gtall);
-  (void)hipEventRecord(ev(h, E + 6), sf);
-  if (sf != sp) (void)hipStreamWaitEvent(sf, ev(h, E + 5), 0);
-  (void)hipEventRecord(ev(h, E + 0), sf);  // every row of panels P0 .. P0+nsub-1 of L is final
-  if (mtT > 0) {
-    (void)hipStreamWaitEvent(sf, ev(h, prevP0 >= 0 ? Eprev + 1 : (size_t)EV_GRAM), 0);
-    launch_gemm_nt(sf, GEMM_RECT, mtT, ntn, W, -1.0, L + CF * ld + C0, ld, L + CE * ld + C0, ld, 1.0, A + CF * ld + CE, ld,
-                   pf);
-  }
-  (void)hipEventRecord(ev(h, E + 7), sf);
-  // ---- bulk (s): the rest of the trailing matrix, lower tiles ----------------------------------------------------------
-  if (mtT > 0) {
-    if (s != sf) (void)hipStreamWaitEvent(s, ev(h, E + 6), 0);
-    launch_gemm_nt(s, GEMM_LOWER, mtT, mtT, W, -1.0, L + CF * ld + C0, ld, L + CF * ld + C0, ld, 1.0, A + CF * ld + CF, ld,
-                   pf);
-  }
-  (void)hipEventRecord(ev(h, E + 1), s);
-}
-
 template <class T>
 static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int next_nsub, hipStream_t st,
                             hipStream_t s2) {
@@ -771,21 +572,7 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
   const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
   // R[0:C0, C0:CE] is final: its last update (the previous super-step's next-columns update)
   // ran on this chain stream, in order
-  if (h->sched == 1) {
-    // super-panel schedule: the diagonal block of Y is T^-T as assembled behind the Cholesky chain (assemble_tinv),
-    // the rows above it ONE product with it: Y[0:C0, C0:CE] = R[0:C0, C0:CE] T^-T
-    const int64_t tld = h->tinv_ld, W = CE - C0;
-    const T *X = reinterpret_cast<const T *>(h->TX) + C0 * tld;
-    launch_transpose_block(st, X, tld, Y + C0 * ld + C0, ld, W);
-    if (C0 > 0) {
-      GemmGrid gtri;  // T^-1 is lower triangular: tile column tj only needs k < (tj + 1) * 128
-      gtri.ktri = h->ktri;
-      gtri.prio = chain_prio_of(h);
-      launch_gemm_nt(st, GEMM_RECT, (int)(C0 / TILE), (int)(W / TILE), W, 1.0, R + C0, ld, X, tld, 0.0, Y + C0, ld,
-                     pf, &gtri);
-    }
-  }
-  for (int q = 0; h->sched != 1 && q < nsub; ++q) {
+  for (int q = 0; q < nsub; ++q) {
     const int p = P0 + q;
     const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
     const T *Dp = reinterpret_cast<const T *>(h->Dinv) + (size_t)p * PANEL * PANEL;
@@ -810,7 +597,7 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
                       -1.0, Y + k0, ld, L + c2 * ld + k0, ld, 1.0, R + c2, ld, pf, &gch);
     }
   }
-  order(h, EV_BASE + EV_PER * P0 + 2, st, s2);  // column panels P0.. of Y are final
+  order(h, EV_BASE + 4 * P0 + 2, st, s2);  // column panels P0.. of Y are final
   const int nt = (int)((npad - CE) / TILE);
   if (nt > 0) {
     const int64_t Kw = CE - C0;
@@ -819,9 +606,11 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
     // The next super-step's columns stay on the CHAIN stream (as in the Cholesky sweep: no
     // event hop on the chain); they were last touched by the previous super-step's bulk update.
     if (P0 > 0 && st != s2)
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + EV_PER * prevP0 + 3), 0);
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * prevP0 + 3), 0);
     // The super-panel of Y is upper triangular in its own block rows C0 .. CE: tile row C0/128 + i only sums
-    // k >= i * 128 (krag0) -- half of the K range of those rows, 0.1 TFLOP of an N = 16384 evaluation.
+    // k >= i * 128 (krag0) -- half of the K range of those rows, 0.1 TFLOP of an N = 16384 evaluation that is
+    // no longer launched (4.58 -> 4.50 TFLOP; the evaluation's time does not move: 71.43 -> 71.35 ms, the
+    // inverse's bulk stream has that much slack behind its chain).
     GemmGrid gch, gbulk;
     gch.prio = chain_prio_of(h);
     if (h->krag) gch.krag0 = gbulk.krag0 = (int)(C0 / TILE);
@@ -832,13 +621,12 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
       launch_gemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
                       R + C3, ld, pf, &gbulk);
     }
-    (void)hipEventRecord(ev(h, EV_BASE + EV_PER * P0 + 3), s2);  // bulk R update of super-step P0 done
+    (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);  // bulk R update of super-step P0 done
   }
 }
 
 template <class T>
 static int factorize_t(gogp_handle *h, bool eager) {
-  const auto t_entry = std::chrono::steady_clock::now();
   const int64_t npad = h->npad, ld = npad;
   hipStream_t s = h->s;
   // without lookahead everything runs in order on the main stream
@@ -869,10 +657,6 @@ static int factorize_t(gogp_handle *h, bool eager) {
   if (rc != GOGP_OK) return rc;
   if (eager) {
     rc = ensure_y(h);
-    if (rc != GOGP_OK) return rc;
-  }
-  if (h->sched == 1) {
-    rc = ensure_tinv(h);
     if (rc != GOGP_OK) return rc;
   }
   // the panel stream joins whatever the main stream still holds from the previous call
@@ -916,13 +700,12 @@ static int factorize_t(gogp_handle *h, bool eager) {
     nsub = superpanel_width(h, npanel, P0);
     const int next_nsub = (P0 + nsub < npanel) ? superpanel_width(h, npanel, P0 + nsub) : 0;
     const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
-    if (h->sched == 1) chol_superpanel<T>(h, P0, nsub, prevP0, next_nsub, sp, h->lookahead ? h->sf : h->s, s);
-    for (int q = 0; h->sched != 1 && q < nsub; ++q) {
+    for (int q = 0; q < nsub; ++q) {
       const int p = P0 + q;
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
       T *Dp = Dinv + (size_t)p * PANEL * PANEL;
       // 256x256 diagonal block: factor + dense inverse, one workgroup
-      chain_diag(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
+      diag_block(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
       const int mt2 = (int)((npad - c2) / TILE);
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
       if (mt2 > 0) {
@@ -949,13 +732,13 @@ static int factorize_t(gogp_handle *h, bool eager) {
                         A + c2 * ld + c2, ld, pf, &gch);
       }
     }
-    if (h->sched != 1) order(h, EV_BASE + EV_PER * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
-    (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + EV_PER * P0), 0);
+    order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
+    if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
     for (int q = 0; q < nsub; ++q)
       launch_trsv_fwd_step(sz, L, ld, Dinv, P0 + q, npanel, h->w, h->z);
     // ---- trailing update, rank nsub*256 ------------------------------------------------------
     const int mtE = (int)((npad - CE) / TILE);
-    if (h->sched != 1 && mtE > 0) {
+    if (mtE > 0) {
       const int64_t Kw = CE - C0;
       const int ntn = mtE < 2 * next_nsub ? mtE : 2 * next_nsub;
       // The next super-panel's block columns, each from its diagonal block down, stay on the
@@ -963,7 +746,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
       // never crosses streams (two event hops of ~15 us per super-panel otherwise).  They
       // only wait for the previous super-panel's bulk update of these columns, which in
       // steady state finished long ago.
-      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + EV_PER * prevP0 + 1 : EV_GRAM), 0);
+      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * prevP0 + 1 : EV_GRAM), 0);
       // ONE trapezoid launch for all of them (rows CE.., columns CE .. CE + ntn*128, the
       // strictly upper 256-blocks -- R of the triangular inverse -- skipped): separate
       // launches would run one after the other on this in-order stream
@@ -977,11 +760,11 @@ static int factorize_t(gogp_handle *h, bool eager) {
         launch_gemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
       }
-      (void)hipEventRecord(ev(h, EV_BASE + EV_PER * P0 + 1), s);  // bulk update of super-panel P0 done
+      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
     }
     // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + EV_PER * P0), 0);
+      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
       trtri_superstep<T>(h, P0, nsub, prevP0, next_nsub, st, s2);
       if (fuse_kinv) {
         // ---- and K^-1 = Y Y^T = sum over the column panels of Y, right behind: the rank-(nsub*256)
@@ -989,7 +772,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
         // C0.. are new: overwritten).  That corner of bufA is dead (panels < CE of L are final) and
         // disjoint from R.  The updates wait for nothing but their panel of Y and grow towards the
         // end of the sweep, where the two chains leave most of the GPU idle: lowest priority.
-        (void)hipStreamWaitEvent(h->sk, ev(h, EV_BASE + EV_PER * P0 + 2), 0);
+        (void)hipStreamWaitEvent(h->sk, ev(h, EV_BASE + 4 * P0 + 2), 0);
         GemmGrid gk;
         gk.new_row0 = (int)(C0 / TILE);
         if (h->krag) gk.krag0 = (int)(C0 / TILE);
@@ -1055,12 +838,6 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipEventRecord(ev(h, EV_ALPHA), sp);
   }
   h->alpha_pending = true;
-  if (h->debug_enqueue) {
-    const double t_enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
-    (void)hipStreamSynchronize(s);
-    const double t_all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
-    fprintf(stderr, "gogp: factorize n=%lld: host enqueue %.3f ms, LML known after %.3f ms\n", (long long)h->n, t_enq, t_all);
-  }
   if (h->batch_mode) {  // the caller synchronises and judges every candidate from its own row of hscal
     h->factored = true;
     h->have_alpha = true;
@@ -1075,8 +852,6 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipStreamSynchronize(s2);
     (void)hipStreamSynchronize(h->sl);
     (void)hipStreamSynchronize(h->sk);
-    (void)hipStreamSynchronize(h->sf);
-    (void)hipStreamSynchronize(h->sq);
     h->alpha_pending = h->kinv_pending = false;
     h->trtri_done = h->trtri_pending = false;
     h->notpd = fr.notpd;
@@ -1365,9 +1140,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int64_t GRAPH_MAX_NPAD = 1024;  // option "graph": linear graphs only (see the capture below)
 
 struct CandLayout {
-  size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, TX, Tmt, total;
+  size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, total;
 };
-static CandLayout cand_layout(int64_t npad, int64_t tld) {
+static CandLayout cand_layout(int64_t npad) {
   CandLayout L;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -1385,8 +1160,6 @@ static CandLayout cand_layout(int64_t npad, int64_t tld) {
   L.alpha = take((size_t)npad * sizeof(double));
   L.gpart = take((size_t)grad_reduce_blocks(npad) * NACC * sizeof(double));
   L.Dinv = take((size_t)(npad / PANEL) * PANEL * PANEL * sizeof(double));
-  L.Tmt = take((size_t)TMT_BLOCKS * PANEL * PANEL * sizeof(double));
-  L.TX = take((size_t)npad * (size_t)tld * sizeof(double));  // super-panel schedule: T^-1 of every super-panel
   L.bufA = take(nn);
   L.bufL = take(nn);
   L.bufY = take(nn);
@@ -1407,8 +1180,7 @@ static int ensure_candidates(gogp_handle *h, int k) {
                             hipHostMallocDefault));
     h->cand_host_k = k;
   }
-  const int64_t tld = (int64_t)tinv_panels(h) * PANEL;
-  if (k > h->cand_cap_k || h->npad > h->cand_cap_npad || tld != h->cand_tld) {
+  if (k > h->cand_cap_k || h->npad > h->cand_cap_npad) {
     // a captured graph holds raw pointers into the arena at the OLD stride: a new arena may come back
     // at the same address with another slot size, which the pointer comparison alone would not notice
     drop_cand_graph(h);
@@ -1417,9 +1189,8 @@ static int ensure_candidates(gogp_handle *h, int k) {
     h->cand_cap_k = 0;
     h->cand_cap_npad = 0;
     const int64_t cap = std::max(h->npad, h->cand_cap_npad);
-    const CandLayout L = cand_layout(cap, tld);
+    const CandLayout L = cand_layout(cap);
     HIPCHK(h, hipMalloc((void **)&h->cand_arena, L.total * (size_t)k));
-    h->cand_tld = tld;
     h->cand_stride = L.total;
     h->cand_cap_k = k;
     h->cand_cap_npad = cap;
@@ -1457,19 +1228,16 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   struct Saved {
     DevParams *devP;
     long long *info;
-    double *scalars, *gout, *bufA, *bufL, *bufY, *Dinv, *z, *w, *alpha, *gpart, *hscal, *TX, *Tmt;
-    int64_t cap_y, notpd, tinv_ld;
+    double *scalars, *gout, *bufA, *bufL, *bufY, *Dinv, *z, *w, *alpha, *gpart, *hscal;
+    int64_t cap_y, notpd;
     bool factored, have_alpha, have_kinv, observed, with_obs, grad_valid, trtri_done;
     double lml, cond_lb;
     std::vector<double> theta_s, theta_n;
   } sv{h->devP, h->info, h->scalars, h->gout, h->bufA, h->bufL, h->bufY, h->Dinv, h->z, h->w, h->alpha,
-       h->gpart, h->hscal, h->TX, h->Tmt, h->cap_y, h->notpd, h->tinv_ld, h->factored, h->have_alpha, h->have_kinv, h->observed,
+       h->gpart, h->hscal, h->cap_y, h->notpd, h->factored, h->have_alpha, h->have_kinv, h->observed,
        h->with_obs, h->grad_valid, h->trtri_done, h->lml, h->cond_lb, h->theta_s, h->theta_n};
-  const CandLayout L = cand_layout(h->cand_cap_npad, h->cand_tld);
+  const CandLayout L = cand_layout(h->cand_cap_npad);
   char *a0 = h->cand_arena;
-  h->TX = (double *)(a0 + L.TX);
-  h->Tmt = (double *)(a0 + L.Tmt);
-  h->tinv_ld = h->cand_tld;
   h->devP = (DevParams *)(a0 + L.devP);
   h->info = (long long *)(a0 + L.info);
   h->scalars = (double *)(a0 + L.scalars);
@@ -1521,8 +1289,8 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
     // every stream joins the main one (the end of a captured graph; harmless otherwise)
-    size_t slot = EV_BASE + EV_PER * (size_t)(h->npad / PANEL);  // the four event slots behind the panels' own
-    for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sk, h->sf, h->sq}) order(h, slot++, q, h->s);
+    size_t slot = EV_BASE + 4 * (size_t)(h->npad / PANEL);  // the four event slots behind the panels' own
+    for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sk}) order(h, slot++, q, h->s);
     return GOGP_OK;
   };
   auto run = [&]() -> int {
@@ -1530,7 +1298,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     const bool graph = h->use_graph && !h->prof.on && h->npad <= GRAPH_MAX_NPAD;
     auto &key = h->cand_graph_key;
     auto same = [&](const decltype(h->cand_graph_key) &q) {
-      return q.k == k && q.n == h->n && q.superpanel == h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 65536 * h->sched && q.arena == h->cand_arena &&
+      return q.k == k && q.n == h->n && q.superpanel == h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining && q.arena == h->cand_arena &&
              q.stride == h->cand_stride && q.cap_npad == h->cand_cap_npad && q.kinv_fused == h->kinv_fused &&
              q.dX == h->dX && q.dy == h->dy && q.hostP == h->cand_hostP && q.hscal == h->cand_hscal;
     };
@@ -1540,7 +1308,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     const bool seen = graph && same(h->cand_seen_key);
     h->cand_seen_key.k = k;
     h->cand_seen_key.n = h->n;
-    h->cand_seen_key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 65536 * h->sched;
+    h->cand_seen_key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
     h->cand_seen_key.arena = h->cand_arena;
     h->cand_seen_key.stride = h->cand_stride;
     h->cand_seen_key.cap_npad = h->cand_cap_npad;
@@ -1558,8 +1326,8 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         // end on the sweep's fork / join pattern across streams, so the graph path is limited to
         // sizes where the evaluation is a single dependent chain anyway (see the caller).
         HIPCHK(h, graph_stream(h));
-        hipStream_t keep[8] = {h->s, h->sp, h->s2, h->st, h->sl, h->sk, h->sf, h->sq};
-        h->s = h->sp = h->s2 = h->st = h->sl = h->sk = h->sf = h->sq = h->sg;
+        hipStream_t keep[6] = {h->s, h->sp, h->s2, h->st, h->sl, h->sk};
+        h->s = h->sp = h->s2 = h->st = h->sl = h->sk = h->sg;
         const hipError_t eb = hipStreamBeginCapture(h->sg, hipStreamCaptureModeRelaxed);
         hipError_t ec = eb;
         if (eb == hipSuccess) {
@@ -1572,8 +1340,6 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         h->st = keep[3];
         h->sl = keep[4];
         h->sk = keep[5];
-        h->sf = keep[6];
-        h->sq = keep[7];
         if (r != GOGP_OK) {
           if (gr) (void)hipGraphDestroy(gr);
           return r;
@@ -1584,7 +1350,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         HIPCHK(h, ei);
         key.k = k;
         key.n = h->n;
-        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 65536 * h->sched;
+        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
         key.arena = h->cand_arena;
         key.stride = h->cand_stride;
         key.cap_npad = h->cand_cap_npad;
@@ -1651,9 +1417,6 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   h->alpha = sv.alpha;
   h->gpart = sv.gpart;
   h->hscal = sv.hscal;
-  h->TX = sv.TX;
-  h->Tmt = sv.Tmt;
-  h->tinv_ld = sv.tinv_ld;
   h->cap_y = sv.cap_y;
   h->notpd = sv.notpd;
   h->factored = sv.factored;
@@ -2013,23 +1776,6 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   // a captured launch sequence of the candidates path was recorded under the old options: every option decides
   // what enqueue() launches (or may, later), so none of them keeps the graph
   drop_cand_graph(h);
-  if (strcmp(name, "debug_enqueue") == 0) {  // diagnostic: host time of the enqueue of one factorisation, to stderr
-    h->debug_enqueue = value != 0;
-    return GOGP_OK;
-  }
-  if (strcmp(name, "diag_early") == 0) {  // -1: by size, 0: off, 1: on (diag256.hip: diag256_wait_kernel)
-    h->diag_early = value < 0 ? -1 : (value != 0);
-    return GOGP_OK;
-  }
-  if (strcmp(name, "sched") == 0) {  // 1: super-panel schedule (default), 0: panel schedule of rounds 1-3
-    if (value != 0 && value != 1) return fail(h, GOGP_EARG, "sched must be 0 or 1");
-    HIPCHK(h, hipSetDevice(h->device));
-    for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
-    h->sched = (int)value;
-    h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;  // a lazy inverse must not mix schedules
-    h->trtri_done = h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
-    return GOGP_OK;
-  }
   if (strcmp(name, "krag") == 0) {  // the inverse's updates skip the zero triangle of a super-panel of Y
     h->krag = value != 0;
     return GOGP_OK;

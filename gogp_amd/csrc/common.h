@@ -199,11 +199,6 @@ void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double
 // failure wins).
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
-// the same dispatched early: the workgroup takes its CU, then polls *flag until it reaches `want` (raised by
-// launch_flag_raise behind the producer of the block); a poll that runs out sets *info = -2
-void launch_diag256_wait(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv,
-                         int64_t row0, int64_t nvalid, long long *info, const long long *flag, long long want);
-void launch_flag_raise(hipStream_t s, long long *flag, long long v);
 // the same with Dinv written into a 256x256 sub-block of a matrix of leading dimension 512
 void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                           double *Dinv, int64_t row0, int64_t nvalid, long long *info);
@@ -261,21 +256,6 @@ void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const doubl
                          int64_t npad, double *alpha);
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
-// super-panel schedule (api.hip: assemble_tinv): diagonal blocks / zero blocks of T^-1 and T^-T; strided block copy
-void launch_tinv_init(hipStream_t s, const double *Dinv, double *X, double *XT, int nsub, int64_t tld);
-void launch_tinv_init(hipStream_t s, const float *Dinv, float *X, float *XT, int nsub, int64_t tld);
-void launch_copy_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd, int64_t rows,
-                       int64_t cols);
-void launch_copy_block(hipStream_t s, const float *src, int64_t lds_, float *dst, int64_t ldd, int64_t rows,
-                       int64_t cols);
-// nprod (<= 6) products C_b (256 x 256) = alpha A_b (256 x K_b) B_b (K_b x 256), row-major, in one launch (solve.hip)
-void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
-                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha);
-void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
-                    const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha);
-// dst (n x n, ldd) = src^T
-void launch_transpose_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd, int64_t n);
-void launch_transpose_block(hipStream_t s, const float *src, int64_t lds_, float *dst, int64_t ldd, int64_t n);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b

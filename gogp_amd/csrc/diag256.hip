@@ -611,64 +611,6 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
   diag256_body<DO_POTRF, STAMP, LDD>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, stamps);
 }
 
-#ifndef GOGP_BUILD_TESTHOOKS
-// The same kernel dispatched EARLY (api.hip, option "diag_early"): it is launched on its own stream without waiting
-// for the update that produces its block, takes its CU -- the workgroup needs all 152 KB of LDS and every VGPR of
-// one, and under the bulk updates it waited 150-400 us (up to 2 ms) for two co-resident bulk workgroups to leave
-// together, on the critical chain, 64 times per N = 16384 evaluation -- and then polls a device flag that a
-// one-thread kernel behind the producing update raises.  Only the INPUT side is a flag (an acquire: L2
-// invalidate, no write-back); the results leave through the normal end of the kernel, so no in-kernel release.
-// Every wave reaches the exit: the poll is bounded (~2 s of the 100 MHz clock), a timeout is reported through
-// *info = -2 and the block is not touched.
-template <int LDD>
-__global__ __launch_bounds__(NT) void diag256_wait_kernel(const double *A, long ld, double *__restrict__ Lout,
-                                                          long ldl, double *__restrict__ Dinv, long row0,
-                                                          long nvalid, long long *info, const long long *flag,
-                                                          long long want, long bstride) {
-  __shared__ __attribute__((aligned(16))) double S[128 * SLD];
-  __shared__ __attribute__((aligned(16))) double G[GSIZE];
-  __shared__ double rinv_s[8 * 16];
-  __shared__ int timed_out;
-  if (threadIdx.x == 0) {
-    int bad = 0;
-    const unsigned long long t0 = wall_clock64();
-    unsigned polls = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(20);
-      if ((++polls & 1023u) == 0 && wall_clock64() - t0 > 200000000ull) {  // 2 s of the 100 MHz counter
-        bad = 1;
-        break;
-      }
-    }
-    timed_out = bad;
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the producer finished before the flag was raised
-  A = gogp::cand(A, bstride);
-  if (Lout) Lout = gogp::cand(Lout, bstride);
-  Dinv = gogp::cand(Dinv, bstride);
-  if (info) info = gogp::cand(info, bstride);
-  if (timed_out) {
-    if (threadIdx.x == 0 && info) *info = -2;
-    return;
-  }
-  diag256_body<true, false, LDD>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, nullptr);
-}
-
-void launch_diag256_wait(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv,
-                         int64_t row0, int64_t nvalid, long long *info, const long long *flag, long long want) {
-  hipLaunchKernelGGL((diag256_wait_kernel<256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s, A, (long)ld,
-                     Lout, (long)ldl, Dinv, (long)row0, (long)nvalid, info, flag, want, gogp::tl_batch.stride);
-}
-
-__global__ void flag_raise_kernel(long long *flag, long long v) {
-  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-void launch_flag_raise(hipStream_t s, long long *flag, long long v) {
-  hipLaunchKernelGGL(flag_raise_kernel, dim3(1), dim3(1), 0, s, flag, v);
-}
-#endif
-
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
   hipLaunchKernelGGL((diag256_kernel<true, false, 256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s,

@@ -54,7 +54,6 @@ struct gogp_handle {
   size_t cand_stride = 0;       // bytes per slot
   int cand_cap_k = 0;
   int64_t cand_cap_npad = 0;
-  int64_t cand_tld = 0;         // leading dimension of the slots' T^-1 stores (super-panel schedule)
   DevParams *cand_hostP = nullptr;  // pinned, cand_host_k entries
   double *cand_hscal = nullptr;     // pinned, cand_host_k x (NACC + 16) doubles
   int cand_host_k = 0;
@@ -77,13 +76,6 @@ struct gogp_handle {
   hipStream_t s2 = nullptr;  // big updates of the triangular inverse (fused sweep)
   hipStream_t st = nullptr;  // its chain: column panels of Y = L^-T
   hipStream_t sk = nullptr;  // rank-k updates K^-1 (+)= Y_P Y_P^T behind the inverse (low priority)
-  hipStream_t sq = nullptr;  // option "diag_early": the diagonal-block kernels, dispatched ahead of their input (diag256.hip)
-  long long *dflag = nullptr;  // ... and the device flag they poll; flag_seq: the last value raised / waited for
-  long long flag_seq = 0;
-  int debug_enqueue = 0;
-  int diag_early = -1;         // -1: by size (npad >= 2048), 0: off, 1: on
-  hipStream_t sf = nullptr;  // super-panel schedule: the full-height part of a super-panel (solve below the head, next
-                             // columns below the head), between the diagonal chain (sp) and the bulk update (s)
   void *stream_set = nullptr;  // the pooled StreamSet the five streams belong to
   std::vector<hipEvent_t> evs;  // cross-stream ordering events (timing disabled)
   int lookahead = 1;
@@ -94,14 +86,6 @@ struct gogp_handle {
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
-  // option "sched" (api.hip, factorize_t): 1 = super-panel schedule -- the chain only factors the W x W diagonal
-  // block of a super-panel (W = 256 * panels) and assembles its inverse T^-1; every full-height step is ONE product
-  // with T^-T.  0 = the panel schedule of rounds 1-3 (panel solve and update per 256 columns on the chain).
-  int sched = 0;
-  double *TX = nullptr;                  // T^-1 (lower) of every super-panel: rows C0.. of an npad x tinv_ld matrix
-  double *Tmt = nullptr;                 // 256 x 256 scratch blocks of the assembly
-  int64_t tinv_ld = 0;                   // leading dimension = widest super-panel the options allow
-  size_t cap_tinv = 0;                   // elements allocated per buffer
   int krag = 1;                // the inverse's updates skip the zero triangle of a super-panel of Y (common.h: GemmGrid::krag0)
   int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the
                                // gradient on the matrix cores (grad_mfma.hip); 65: never
@@ -170,8 +154,8 @@ struct AuxTimer {
   } while (0)
 
 // every work stream of the handle (the communication stream of a sharded handle is dist2d's)
-static inline std::array<hipStream_t, 8> work_streams(const gogp_handle *h) {
-  return {h->s, h->sp, h->s2, h->st, h->sl, h->sk, h->sf, h->sq};
+static inline std::array<hipStream_t, 6> work_streams(const gogp_handle *h) {
+  return {h->s, h->sp, h->s2, h->st, h->sl, h->sk};
 }
 
 static inline int fail(gogp_handle *h, int code, const char *msg) {
@@ -182,13 +166,9 @@ static inline int fail(gogp_handle *h, int code, const char *msg) {
 // ---- cross-stream events -----------------------------------------------------------------
 enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_KINV = 7,
        EV_YDONE = 8,  // Y is final (EV_TRTRI: everything on the inverse's chain stream is done, alpha = Y z included)
-       EV_DIAG = 9,   // a diagonal block dispatched early (stream sq) is done
-       EV_BASE = 10 };
-// per super-panel starting at panel p: EV_BASE + EV_PER * p + {0: its panels of L final (all rows), 1: bulk update
-// of the trailing matrix done, 2: its column panels of Y final, 3: bulk update of R done; super-panel schedule:
-// 4: T^-1 assembled, 5: head done (L[CE:CF, C0:CE] and the next diagonal block's update), 6: L[CF:, C0:CE] final,
-// 7: next columns below the head updated}
-constexpr size_t EV_PER = 8;
+       EV_BASE = 9 };
+// per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
+//                              2: column panel p of Y final, 3: next column panel of R final}
 static inline hipEvent_t ev(gogp_handle *h, size_t i) {
   while (h->evs.size() <= i) {
     hipEvent_t e = nullptr;
