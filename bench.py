@@ -453,6 +453,7 @@ def main():
     prec = 32 if wl.dtype == "f32" else 64
     dtype = "f32" if prec == 32 else "f64"
     peak = FP32_PEAK_TFLOPS if prec == 32 else FP64_PEAK_TFLOPS
+    esz = 4.0 if prec == 32 else 8.0  # bytes per element of the N x N matrices
     X, y = wl.inputs()
     simil, noise = wl.simil, wl.noise
     cps = args.candidates_per_step
@@ -647,8 +648,10 @@ def main():
             out["roofline"]["traffic_note"] = "not reported: " + (why or "measured at another size / on one GPU only")
         if gram_n and grad_n:
             w = 512  # the first super-panel's block columns are built on the panel stream
-            gram_bytes = 8.0 * max(0, N - w) ** 2 / 2.0 * cps
-            grad_bytes = 8.0 * float(N) * N / 2.0 * cps
+            # bytes per matrix element: 8 (fp64 path) or 4 (precision = 32: K, K^-1 are float) -- round 3 counted 8
+            # on both paths and overstated config 5's GB/s twofold
+            gram_bytes = esz * max(0, N - w) ** 2 / 2.0 * cps
+            grad_bytes = esz * float(N) * N / 2.0 * cps
             out["hbm_bound_kernels"] = {
                 "gram_build": {"algorithmic_bytes": gram_bytes, "ms": gram_ms / gram_n,
                                "GBps": gram_bytes / (gram_ms / gram_n * 1e-3) / 1e9,
@@ -656,7 +659,8 @@ def main():
                 "grad_reduce": {"algorithmic_bytes": grad_bytes, "ms": grad_ms / grad_n,
                                 "GBps": grad_bytes / (grad_ms / grad_n * 1e-3) / 1e9,
                                 "frac_of_hbm_peak": grad_bytes / (grad_ms / grad_n * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "note": "8 B per lower-triangle element written (Gram; the part built on the main "
+                "bytes_per_element": esz,
+                "note": "8 B (fp64 path; 4 B with precision = 32) per lower-triangle element written (Gram; the part built on the main "
                         "stream) / read (K^-1 in the fused gradient reduction); HIP events on the "
                         "kernel's stream"}
         if cps > 1 and N <= 1024:
@@ -756,23 +760,44 @@ def main():
             # secondary metric: Produce throughput at the same N, M = 1024 fresh
             # test points per call, host Z in / host mu, sigma out -- outside the timed region
             M = 1024 if N >= 1024 else 16
-            Zp = wl.test_points(M)
-            g.Produce(Zp)
-            torch.cuda.synchronize()
-            g.profile_enable(True)
-            tp = time.perf_counter()
-            for _ in range(3):
-                mu_p, sigma_p = g.Produce(Zp)
-            tp = (time.perf_counter() - tp) / 3
-            cross_ms, cross_n = g.profile_read_aux(2)
-            g.profile_enable(False)
-            out["produce"] = {"m": M, "ms_per_call": tp * 1e3, "test_points_per_s": M / tp,
-                              "note": "Kstar build + mu = Kstar^T alpha + blocked solve V^T = Kstar^T L^-T "
-                                      "(N^2 M flop on the tile kernel) + column norms, factor resident"}
-            if cross_n:
-                cb = 8.0 * N * M
-                out["produce"]["cross_kernel"] = {"algorithmic_bytes": cb, "ms": cross_ms / cross_n,
-                                                  "GBps": cb / (cross_ms / cross_n * 1e-3) / 1e9}
+
+            def time_produce(m, reps=3):
+                """One Produce call of m fresh test points (host Z in, host mu / sigma out), profiling events on
+                its tile-kernel launches: wall time per call, union of the launch intervals, launched flops."""
+                Zm = wl.test_points(m)
+                g.Produce(Zm)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    g.Produce(Zm)
+                t = (time.perf_counter() - t) / reps  # wall time per call, no events on the launches
+                g.profile_enable(True)
+                for _ in range(reps):
+                    g.Produce(Zm)
+                cross_ms, cross_n = g.profile_read_aux(2)
+                _, launches, flops, busy_ms = g.profile_read()
+                g.profile_enable(False)
+                # algorithmic work of the solve (gp/gp.go:337-342 as ONE triangular solve, SURVEY 8d): N^2 M flop
+                alg = float(N) * N * m
+                d = {"m": m, "ms_per_call": t * 1e3, "test_points_per_s": m / t,
+                     "roofline": {"bound": "mfma", "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": alg / t / 1e12 / peak,
+                                  "algorithmic_flops_per_call": alg,
+                                  "kernel_busy_ms_per_call": busy_ms / reps,
+                                  "frac_while_kernel_runs": (alg / (busy_ms / reps * 1e-3) / 1e12 / peak) if busy_ms else None,
+                                  "launches_per_call": launches / reps, "launched_flops_per_call": flops / reps}}
+                if cross_n:
+                    cb = esz * N * m
+                    d["cross_kernel"] = {"algorithmic_bytes": cb, "ms": cross_ms / cross_n,
+                                         "GBps": cb / (cross_ms / cross_n * 1e-3) / 1e9}
+                return d
+
+            out["produce"] = time_produce(M)
+            out["produce"]["note"] = ("Kstar build + mu = Kstar^T alpha + blocked solve V^T = Kstar^T L^-T (N^2 M flop on the "
+                                      "tile kernel, the test points' tile rows on up to 4 independent chains) + column "
+                                      "norms, factor resident; roofline.frac = N^2 M / wall time of the whole call")
+            if N >= 4096:
+                out["produce"]["m_sweep"] = [time_produce(m, reps=2) for m in (1, 64, 8192)]
         out_holder["line"] = out
         out_holder["measurement_done"] = True  # on every rank: the replica value needs nothing collective any more
 

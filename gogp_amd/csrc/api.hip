@@ -96,6 +96,11 @@ static void free_n_buffers(gogp_handle *h) {
   (void)hipFree(h->rz);
   (void)hipFree(h->rd);
   (void)hipFree(h->rpart);
+  (void)hipFree(h->TX);
+  (void)hipFree(h->Tmt);
+  h->TX = h->Tmt = nullptr;
+  h->cap_tinv = 0;
+  h->tinv_valid = h->tinv_pending = false;
   h->rw = h->rz = h->rd = h->rpart = nullptr;
   h->dX = h->dy = h->bufA = h->bufL = h->bufY = h->Dinv = nullptr;
   h->z = h->w = h->alpha = h->gpart = nullptr;
@@ -358,6 +363,7 @@ static int set_data_impl(gogp_handle *h, const double *X, const double *y, int64
   // replaced or re-filled
   for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
+  h->tinv_valid = h->tinv_pending = false;
   if (h->dist) {
     const int rcs = gogp_dist_sync(h);
     if (rcs != GOGP_OK) return rcs;
@@ -562,6 +568,74 @@ static inline int superpanel_width(const gogp_handle *h, int npanel, int P0) {
   return (npanel - P0 < sw) ? npanel - P0 : sw;
 }
 
+// ---- T^-1 of the super-panels' diagonal blocks (for Produce) --------------------------------------------------------
+// widest super-panel (in 256-panels) the options allow = leading dimension of the T^-1 store
+constexpr int TMT_BLOCKS = 8;  // scratch blocks M of one block diagonal (super-panels are at most 8 panels wide)
+// Produce blocks the substitution by its own super-panels of `produce_panels` 256-panels (T^-1 is assembled by Produce,
+// so its blocking is independent of the factorisation's)
+static inline int tinv_panels(const gogp_handle *h) { return h->produce_panels; }
+static inline int64_t tinv_signature(const gogp_handle *h) {
+  return (int64_t)h->produce_panels + (h->npad << 8) + ((int64_t)h->prec << 56);
+}
+static int ensure_tinv(gogp_handle *h) {
+  const int64_t tld = (int64_t)tinv_panels(h) * PANEL;
+  const size_t need = (size_t)std::max(h->npad, h->cap_npad) * (size_t)tld;
+  if (!h->TX || h->cap_tinv < need) {
+    (void)hipFree(h->TX);
+    (void)hipFree(h->Tmt);
+    h->TX = h->Tmt = nullptr;
+    h->cap_tinv = 0;
+    HIPCHK(h, hipMalloc(&h->TX, need * h->esz()));
+    HIPCHK(h, hipMalloc(&h->Tmt, (size_t)TMT_BLOCKS * PANEL * PANEL * h->esz()));
+    h->cap_tinv = need;
+  }
+  h->tinv_ld = tld;  // every block that is read is written by the same assembly: a new ld needs no clearing
+  return GOGP_OK;
+}
+
+// X = T^-1 (lower, row-major, ld tinv_ld) of the super-panel starting at panel P0, from its 256-block inverses and the
+// factor's blocks inside it:  X_ii = Dinv_i,  X_ij = -Dinv_i sum_{k=j}^{i-1} L_ik X_kj  (i > j), block diagonal by
+// block diagonal: all blocks at distance d = i - j in two launches of the batched 256-block product (solve.hip:
+// blockmm_kernel: M = L[i, j..i-1] X[j..i-1, j], then X_ij = -Dinv_i M) -- 1 + 2 (panels - 1) tiny launches.
+template <class T>
+static void assemble_tinv(gogp_handle *h, hipStream_t sp, int P0, int nsub) {
+  const int64_t ld = h->npad, tld = h->tinv_ld, C0 = (int64_t)P0 * PANEL;
+  T *X = reinterpret_cast<T *>(h->TX) + C0 * tld;
+  T *MT = reinterpret_cast<T *>(h->Tmt);
+  const T *L = reinterpret_cast<const T *>(h->bufL);
+  const T *Dinv = reinterpret_cast<const T *>(h->Dinv) + (size_t)P0 * PANEL * PANEL;
+  launch_tinv_init(sp, Dinv, X, (T *)nullptr, nsub, tld);
+  for (int d = 1; d < nsub; ++d) {
+    const int cnt = nsub - d;  // blocks (i, i - d), i = d .. nsub-1
+    for (int b0 = 0; b0 < cnt; b0 += 6) {
+      const int nb = std::min(6, cnt - b0);
+      const T *A1[6], *B1[6], *A2[6], *B2[6];
+      T *C1[6], *C2[6];
+      int64_t lda1[6], ldb1[6], ldc1[6], lda2[6], ldb2[6], ldc2[6];
+      int K1[6], K2[6];
+      for (int b = 0; b < nb; ++b) {
+        const int i = d + b0 + b, j = i - d;
+        A1[b] = L + (C0 + (int64_t)i * PANEL) * ld + C0 + (int64_t)j * PANEL;
+        lda1[b] = ld;
+        B1[b] = X + (int64_t)j * PANEL * tld + (int64_t)j * PANEL;
+        ldb1[b] = tld;
+        C1[b] = MT + (size_t)(b0 + b) * PANEL * PANEL;
+        ldc1[b] = PANEL;
+        K1[b] = d * PANEL;
+        A2[b] = Dinv + (size_t)i * PANEL * PANEL;
+        lda2[b] = PANEL;
+        B2[b] = C1[b];
+        ldb2[b] = PANEL;
+        C2[b] = X + (int64_t)i * PANEL * tld + (int64_t)j * PANEL;
+        ldc2[b] = tld;
+        K2[b] = PANEL;
+      }
+      launch_blockmm(sp, nb, A1, lda1, B1, ldb1, C1, ldc1, K1, 1.0);
+      launch_blockmm(sp, nb, A2, lda2, B2, ldb2, C2, ldc2, K2, -1.0);
+    }
+  }
+}
+
 template <class T>
 static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int next_nsub, hipStream_t st,
                             hipStream_t s2) {
@@ -683,6 +757,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
+  if (!h->batch_mode) h->tinv_valid = false;  // Produce assembles T^-1 of the new factor on its first call
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
   HIPCHK(h, cand_copy_in(h, h->w, h->dy, (size_t)npad * sizeof(double), sp));
@@ -734,6 +809,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     }
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
     if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
+
     for (int q = 0; q < nsub; ++q)
       launch_trsv_fwd_step(sz, L, ld, Dinv, P0 + q, npanel, h->w, h->z);
     // ---- trailing update, rank nsub*256 ------------------------------------------------------
@@ -786,6 +862,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipEventRecord(ev(h, EV_KINV), h->sk);
     h->kinv_pending = true;
   }
+
   h->ydone_valid = false;
   if (eager) {
     (void)hipEventRecord(ev(h, EV_TRTRI), st);
@@ -853,6 +930,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)hipStreamSynchronize(h->sl);
     (void)hipStreamSynchronize(h->sk);
     h->alpha_pending = h->kinv_pending = false;
+    h->tinv_valid = h->tinv_pending = false;
     h->trtri_done = h->trtri_pending = false;
     h->notpd = fr.notpd;
     h->err = fr.msg;
@@ -1220,7 +1298,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   // nothing of the handle's own evaluation may still be running: its streams and events are reused
   for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   if (h->kinv_pending) h->have_kinv = true;  // the handle's own K^-1 finished accumulating
-  h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
+  h->trtri_pending = h->alpha_pending = h->kinv_pending = h->tinv_pending = false;
   int rc = ensure_candidates(h, k);
   if (rc != GOGP_OK) return rc;
 
@@ -1451,6 +1529,7 @@ static int ensure_m(gogp_handle *h, int64_t m, int64_t mpad) {
   return GOGP_OK;
 }
 
+constexpr int PRODUCE_GROUPS = 4;
 // Kstar, mean and the blocked solve of Produce on matrices of element type T
 template <class T>
 static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad, double *dmu, double *dq) {
@@ -1464,32 +1543,76 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
   // mean = Kstar^T alpha (gp/gp.go:335)
   launch_rownorm_dot(s, R, ld, h->alpha, npad, m, dmu, nullptr);
   // V^T = Kstar^T L^-T by blocked substitution on the GEMM kernel
-  GemmProfile *pf = nullptr;  // Produce launches are not part of the Observe+Gradient metric
+  // Produce launches are not part of the Observe+Gradient metric: they are event-timed only when the caller enabled
+  // profiling around Produce itself (bench.py: the `produce.roofline` field)
+  GemmProfile *pf = h->prof.on ? &h->prof : nullptr;
   const int mt = (int)(mpad / TILE);
   const int npanel = (int)(npad / PANEL);
+  const int pw = h->produce_panels;  // super-panel width of the substitution, in 256-panels
   // in super-panels, as the factorisation: the panels of a super-panel are solved one after the other
   // (each updating the columns that are left inside it), the trailing columns then receive ONE update
   // with K = 256 * width instead of one K = 256 update per panel (M = 1024: N = 16384 6.74 -> 6.64 ms,
-  // N = 32768 23.0 -> 21.7 ms; with M = 1024 a launch is only 8 tile rows tall, the chain of dependent
-  // launches is what the call costs)
-  for (int P0 = 0, nsub = 0; P0 < npanel; P0 += nsub) {
-    nsub = superpanel_width(h, npanel, P0);
-    const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
-    for (int q = 0; q < nsub; ++q) {
-      const int64_t c0 = C0 + (int64_t)q * PANEL, c2 = c0 + PANEL;
-      const T *Dp = Dinv + (size_t)(P0 + q) * PANEL * PANEL;
-      GemmGrid gtri;
-      gtri.ktri = h->ktri;
-      launch_gemm_nt(s, GEMM_RECT, mt, 2, PANEL, 1.0, R + c0, ld, Dp, PANEL, 0.0, V + c0, ld, pf, &gtri);
-      if (c2 < CE)
-        launch_gemm_nt(s, GEMM_RECT, mt, (int)((CE - c2) / TILE), PANEL, -1.0, V + c0, ld, L + c2 * ld + c0, ld,
-                       1.0, R + c2, ld, pf);
+  // N = 32768 23.0 -> 21.7 ms).  The test points are independent of each other: their tile rows go to up to
+  // PRODUCE_GROUPS streams, each running the whole substitution for its rows -- with M = 1024 one chain is 8 tile
+  // rows tall and its ~130 dependent launches, not the N^2 M flops, are what the call costs; several chains fill
+  // each other's gaps (option "produce_groups", default 2; 1 = round 3's single chain).
+  // T^-1 of every super-panel's diagonal block: assembled by the first Produce on a factor (a chain of tiny launches
+  // on stream sk that runs ahead of the solves, which wait for their super-panel's event), kept for the later ones.
+  // Not behind the factorisation: its 110 launches cost an N = 16384 Observe + Gradient 0.6 ms (measured).
+  const bool use_tinv = h->produce_tinv && h->lookahead && ensure_tinv(h) == GOGP_OK;
+  const bool assemble = use_tinv && !(h->tinv_valid && h->tinv_sig == tinv_signature(h));
+  const size_t evt0 = EV_BASE + 4 * (size_t)npanel + 8 + 2 * PRODUCE_GROUPS;  // one event per super-panel behind the others
+  if (assemble) {
+    order(h, EV_TINV, s, h->sk);  // behind whatever last wrote the factor (s is ordered behind the factorisation)
+    for (int P0 = 0, nsub = 0; P0 < npanel; P0 += nsub) {
+      nsub = std::min(pw, npanel - P0);
+      assemble_tinv<T>(h, h->sk, P0, nsub);
+      (void)hipEventRecord(ev(h, evt0 + (size_t)P0), h->sk);
     }
-    const int nt = (int)((npad - CE) / TILE);
-    if (nt > 0)
-      launch_gemm_nt(s, GEMM_RECT, mt, nt, CE - C0, -1.0, V + C0, ld, L + CE * ld + C0, ld, 1.0,
-                     R + CE, ld, pf);
+    h->tinv_valid = true;
+    h->tinv_sig = tinv_signature(h);
   }
+  hipStream_t gs[PRODUCE_GROUPS] = {s, h->s2, h->st, h->sp};
+  int ngroups = h->lookahead ? std::min(h->produce_groups, std::min(mt, PRODUCE_GROUPS)) : 1;
+  if (ngroups < 1) ngroups = 1;
+  const size_t ev0 = EV_BASE + 4 * (size_t)npanel + 8;  // behind the factorisation's own event slots
+  for (int g = 1; g < ngroups; ++g) order(h, ev0 + g, s, gs[g]);  // Kstar^T (and whatever s held) first
+  for (int g = 0; g < ngroups; ++g) {
+    hipStream_t sg = gs[g];
+    const int t0 = (int)((int64_t)mt * g / ngroups), t1 = (int)((int64_t)mt * (g + 1) / ngroups), mtg = t1 - t0;
+    if (mtg <= 0) continue;
+    T *Rg = R + (int64_t)t0 * TILE * ld, *Vg = V + (int64_t)t0 * TILE * ld;
+    for (int P0 = 0, nsub = 0; P0 < npanel; P0 += nsub) {
+      nsub = std::min(pw, npanel - P0);
+      const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
+      GemmGrid gtri, gup;
+      gtri.ktri = h->ktri;
+      gtri.small_below = gup.small_below = h->produce_small_below;
+      if (use_tinv) {
+        if (assemble) (void)hipStreamWaitEvent(sg, ev(h, evt0 + (size_t)P0), 0);
+        // the whole super-panel at once: V[:, C0:CE] = R[:, C0:CE] T^-T with the assembled inverse of the factor's
+        // diagonal block -- the same flops as the panel-by-panel substitution (T^-1 is lower triangular: ktri), 2
+        // dependent launches per super-panel instead of 2 per 256 columns
+        const T *X = reinterpret_cast<const T *>(h->TX) + C0 * h->tinv_ld;
+        launch_gemm_nt(sg, GEMM_RECT, mtg, (int)((CE - C0) / TILE), CE - C0, 1.0, Rg + C0, ld, X, h->tinv_ld, 0.0, Vg + C0,
+                       ld, pf, &gtri);
+      } else {
+        for (int q = 0; q < nsub; ++q) {
+          const int64_t c0 = C0 + (int64_t)q * PANEL, c2 = c0 + PANEL;
+          const T *Dp = Dinv + (size_t)(P0 + q) * PANEL * PANEL;
+          launch_gemm_nt(sg, GEMM_RECT, mtg, 2, PANEL, 1.0, Rg + c0, ld, Dp, PANEL, 0.0, Vg + c0, ld, pf, &gtri);
+          if (c2 < CE)
+            launch_gemm_nt(sg, GEMM_RECT, mtg, (int)((CE - c2) / TILE), PANEL, -1.0, Vg + c0, ld, L + c2 * ld + c0, ld,
+                           1.0, Rg + c2, ld, pf, &gup);
+        }
+      }
+      const int nt = (int)((npad - CE) / TILE);
+      if (nt > 0)
+        launch_gemm_nt(sg, GEMM_RECT, mtg, nt, CE - C0, -1.0, Vg + C0, ld, L + CE * ld + C0, ld, 1.0, Rg + CE, ld, pf,
+                       &gup);
+    }
+  }
+  for (int g = 1; g < ngroups; ++g) order(h, ev0 + PRODUCE_GROUPS + g, gs[g], s);
   // (Kstar^T K^-1 Kstar)_jj = |V_j|^2 : only the diagonal of gp/gp.go:341-342 is read (:356)
   launch_rownorm_dot(s, V, ld, nullptr, npad, m, nullptr, dq);
 }
@@ -1632,6 +1755,7 @@ extern "C" int gogp_set_factor(gogp_handle *h, const double *theta_simil,
   h->have_kinv = false;
   for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
   h->trtri_done = h->trtri_pending = h->kinv_pending = false;
+  h->tinv_valid = false;  // Produce on a restored factor substitutes panel by panel
   if (h->n == 0) return GOGP_OK;
   if (h->dist) return gogp_dist_set_factor(h, Lin, alpha);  // collective: every rank keeps its own tiles
   rc = gogp_upload_params(h);
@@ -1776,6 +1900,25 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   // a captured launch sequence of the candidates path was recorded under the old options: every option decides
   // what enqueue() launches (or may, later), so none of them keeps the graph
   drop_cand_graph(h);
+  if (strcmp(name, "produce_tinv") == 0) {  // Produce solves whole super-panels through T^-1 (assembled behind the factorisation)
+    h->produce_tinv = value != 0;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "produce_panels") == 0) {  // Produce: 256-panels per super-panel of its substitution
+    if (value < 1 || value > 8) return fail(h, GOGP_EARG, "produce_panels must be 1..8");
+    h->produce_panels = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "produce_small_below") == 0) {  // Produce: launches below this many 128-tiles use 64 x 64 tiles
+    if (value < 0) return fail(h, GOGP_EARG, "produce_small_below must be >= 0");
+    h->produce_small_below = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "produce_groups") == 0) {  // Produce: independent substitution chains over the test points' tile rows
+    if (value < 1 || value > PRODUCE_GROUPS) return fail(h, GOGP_EARG, "produce_groups must be 1..4");
+    h->produce_groups = (int)value;
+    return GOGP_OK;
+  }
   if (strcmp(name, "krag") == 0) {  // the inverse's updates skip the zero triangle of a super-panel of Y
     h->krag = value != 0;
     return GOGP_OK;

@@ -86,6 +86,10 @@ struct GemmGrid {
   // range -- row block krag0 + i of A is zero for k < i * 128 (a super-panel of Y = L^-T with its triangular diagonal
   // part: api.hip, trtri_superstep) -- so tile row ti >= krag0 only sums k >= (ti - krag0) * 128.  -1: none.
   int krag0 = -1;
+  // launches with fewer 128-tiles than this use 64 x 64 tiles (default 384).  Alone on the GPU the 64-tile shape wins
+  // up to ~3000 tiles (820 tiles at K = 768: 61 against 51 TFLOP/s); inside an evaluation, beside other streams'
+  // launches, it loses -- so only Produce, which runs alone, raises it.
+  int small_below = 384;
 };
 
 // Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of
@@ -256,6 +260,14 @@ void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const doubl
                          int64_t npad, double *alpha);
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols);
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
+// T^-1 of a super-panel's diagonal block (api.hip: assemble_tinv): diagonal / zero blocks, and nprod (<= 6) products
+// C_b (256 x 256) = alpha A_b (256 x K_b) B_b (K_b x 256), row-major, in one launch (solve.hip)
+void launch_tinv_init(hipStream_t s, const double *Dinv, double *X, double *XT, int nsub, int64_t tld);
+void launch_tinv_init(hipStream_t s, const float *Dinv, float *X, float *XT, int nsub, int64_t tld);
+void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
+                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha);
+void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
+                    const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b

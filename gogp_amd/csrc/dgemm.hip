@@ -432,7 +432,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // 8-wave shape of the 128x128 tile (measured 4-9 % faster there), the rest the 4-wave one.
   // (a batched launch counts the tiles of all its candidates: together they fill the chip)
   const long total_tiles = (long)ntiles * nz;
-  const bool small = (mode != GEMM_LAUUM) && (total_tiles < 384);
+  const bool small = (mode != GEMM_LAUUM) && (total_tiles < (grid ? grid->small_below : 384));
   // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
   if (g.prio == 1 && !small) g.prio = 0;
   if (small) {

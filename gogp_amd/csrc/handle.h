@@ -86,6 +86,18 @@ struct gogp_handle {
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
+  // T^-1 (lower, row-major) of the diagonal block of every super-panel of the factor: rows C0.. of an npad x tinv_ld
+  // matrix, assembled by the first Produce on a factor (api.hip: assemble_tinv, produce_solve_t).  Produce then solves
+  // a super-panel of columns with ONE product instead of a solve + update per 256 columns.
+  double *TX = nullptr, *Tmt = nullptr;  // Tmt: 256 x 256 scratch blocks of the assembly
+  int64_t tinv_ld = 0;
+  size_t cap_tinv = 0;                   // elements allocated for TX
+  int produce_panels = 4;                // 256-panels per super-panel of Produce's substitution
+  int produce_small_below = 1024;        // Produce runs alone on the GPU: 64 x 64 tiles below this many 128-tiles (common.h: GemmGrid)
+  int produce_tinv = 1;                  // option: 0 = Produce substitutes panel by panel (round 3)
+  bool tinv_valid = false, tinv_pending = false;  // assembled for the current factor
+  int64_t tinv_sig = 0;                  // super-panel layout it was assembled for
+  int produce_groups = 2;      // Produce: independent substitution chains (streams) over the test points' tile rows
   int krag = 1;                // the inverse's updates skip the zero triangle of a super-panel of Y (common.h: GemmGrid::krag0)
   int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the
                                // gradient on the matrix cores (grad_mfma.hip); 65: never
@@ -166,7 +178,8 @@ static inline int fail(gogp_handle *h, int code, const char *msg) {
 // ---- cross-stream events -----------------------------------------------------------------
 enum { EV_GRAM = 0, EV_FWD = 1, EV_ALPHA = 2, EV_INIT = 3, EV_TRTRI = 4, EV_W = 5, EV_ENTRY = 6, EV_KINV = 7,
        EV_YDONE = 8,  // Y is final (EV_TRTRI: everything on the inverse's chain stream is done, alpha = Y z included)
-       EV_BASE = 9 };
+       EV_TINV = 9,   // T^-1 of every super-panel assembled (stream sk)
+       EV_BASE = 10 };
 // per panel p: EV_BASE + 4p + {0: panel p of L final, 1: next block column of A final,
 //                              2: column panel p of Y final, 3: next column panel of R final}
 static inline hipEvent_t ev(gogp_handle *h, size_t i) {

@@ -327,7 +327,7 @@ void launch_gemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, dou
       hipLaunchKernelGGL((__VA_ARGS__), (GRID), (BLOCK), 0, s, g);                         \
   } while (0)
   const long wave8_min = 3072;  // as in dgemm.hip; the shape matters less here (N = 32768: 314.1 -> 312.5 ms)
-  const bool small = (mode != GEMM_LAUUM) && (ntiles < 384);
+  const bool small = (mode != GEMM_LAUUM) && (ntiles < (grid ? grid->small_below : 384));
   // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
   if (g.prio == 1 && !small) g.prio = 0;
   if (small) {  // 64x64 tiles for the skinny GEMMs of the panel chain

@@ -384,6 +384,152 @@ void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld) {
   hipLaunchKernelGGL(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld, 0L);
 }
 
+// ---- inverse of a super-panel's triangular diagonal block (api.hip: assemble_tinv) -------------------------------
+// X (lower, row-major, leading dimension tld) = T^-1 of the nsub*256-wide block T = L[C0:CE, C0:CE] of the factor: with
+// it Produce solves a whole super-panel of columns in ONE product (api.hip: produce_solve_t).  This kernel writes what
+// needs no product -- the diagonal 256-blocks (Dinv_i) and zeros above them; the blocks below are written by
+// blockmm_kernel.  (XT: optionally T^-T the same way; unused today.)  One workgroup per 32 x 32 tile.
+template <class T>
+__global__ __launch_bounds__(256) void tinv_init_kernel(const T *__restrict__ Dinv, T *__restrict__ X,
+                                                        T *__restrict__ XT, int nsub, long tld, long bstride) {
+  Dinv = cand(Dinv, bstride);  // candidate batching (common.h: Batch)
+  X = cand(X, bstride);
+  if (XT) XT = cand(XT, bstride);
+  __shared__ T tile[32][33];
+  const int tpr = nsub * 8;  // 32-tiles per row of the block
+  const int bx = blockIdx.x % tpr, by = blockIdx.x / tpr;
+  const int I = by >> 3, J = bx >> 3;  // 256-block row / column
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const long r0 = (long)by * 32, c0 = (long)bx * 32;
+  if (I == J) {
+    const T *D = Dinv + (long)I * 256 * 256 + (long)(by & 7) * 32 * 256 + (bx & 7) * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+      const T v = D[(ty + r) * 256 + tx];
+      X[(r0 + ty + r) * tld + c0 + tx] = v;
+      tile[ty + r][tx] = v;
+    }
+    if (XT) {  // XT block (I, I) = Dinv_I^T: tile (by, bx) of Dinv lands at tile (bx, by)
+      __syncthreads();
+      const long tr0 = (long)I * 256 + (long)(bx & 7) * 32, tc0 = (long)I * 256 + (long)(by & 7) * 32;
+#pragma unroll
+      for (int r = 0; r < 32; r += 8) XT[(tr0 + ty + r) * tld + tc0 + tx] = tile[tx][ty + r];
+    }
+  } else if (I < J) {
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) X[(r0 + ty + r) * tld + c0 + tx] = (T)0;
+  } else if (XT) {
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) XT[(r0 + ty + r) * tld + c0 + tx] = (T)0;
+  }
+}
+void launch_tinv_init(hipStream_t s, const double *Dinv, double *X, double *XT, int nsub, int64_t tld) {
+  hipLaunchKernelGGL(tinv_init_kernel<double>, dim3(nsub * 8 * nsub * 8, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv,
+                     X, XT, nsub, (long)tld, tl_batch.stride);
+}
+void launch_tinv_init(hipStream_t s, const float *Dinv, float *X, float *XT, int nsub, int64_t tld) {
+  hipLaunchKernelGGL(tinv_init_kernel<float>, dim3(nsub * 8 * nsub * 8), dim3(256), 0, s, Dinv, X, XT, nsub, (long)tld, 0L);
+}
+
+// Up to BLOCKMM_MAX products C_b (256 x 256) = alpha * A_b (256 x K_b) * B_b (K_b x 256) in ONE launch, all row-major
+// (plain A B, which the A B^T tile kernel cannot do without transposed copies): the steps of the T^-1 assembly, tiny
+// products whose cost is their launch, so that all blocks of one block diagonal go out together.  One
+// workgroup per 64 x 64 tile of a product; K walked in chunks of 32 with the next chunk's global loads in flight
+// behind the MFMAs of the current one; always fp64 arithmetic (v_mfma_f64_16x16x4_f64), T only on loads / stores.
+constexpr int BLOCKMM_MAX = 6;
+template <class T>
+struct BlockMM {
+  const T *A[BLOCKMM_MAX];
+  const T *B[BLOCKMM_MAX];
+  T *C[BLOCKMM_MAX];
+  long lda[BLOCKMM_MAX], ldb[BLOCKMM_MAX], ldc[BLOCKMM_MAX];
+  int K[BLOCKMM_MAX];
+  double alpha;
+  long bstride;
+};
+typedef double bmm_f64x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__global__ __launch_bounds__(256, 2) void blockmm_kernel(BlockMM<T> g) {
+  constexpr int KC = 32, AS = KC + 1, BS = 64 + 2;
+  __shared__ double As[64 * AS];
+  __shared__ double Bs[KC * BS];
+  const int b = blockIdx.y;
+  const T *A = cand(g.A[b], g.bstride);
+  const T *B = cand(g.B[b], g.bstride);
+  T *C = cand(g.C[b], g.bstride);
+  const long lda = g.lda[b], ldb = g.ldb[b], ldc = g.ldc[b];
+  const int K = g.K[b];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tr = blockIdx.x >> 2, tc = blockIdx.x & 3;  // 64 x 64 tile of the 256 x 256 product
+  A += (long)tr * 64 * lda;
+  B += tc * 64;
+  C += (long)tr * 64 * ldc + tc * 64;
+  // staging maps: A chunk 64 x 32 (thread: row tid >> 2, 8 consecutive k from (tid & 3) * 8);
+  //               B chunk 32 x 64 (thread: k-row tid >> 3, 8 consecutive columns from (tid & 7) * 8)
+  const int ar = tid >> 2, ak = (tid & 3) * 8, bk = tid >> 3, bc = (tid & 7) * 8;
+  double ra[8], rb[8];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = (double)A[(long)ar * lda + k0 + ak + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = (double)B[(long)(k0 + bk) * ldb + bc + i];
+  };
+  bmm_f64x4 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = (bmm_f64x4){0.0, 0.0, 0.0, 0.0};
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) As[ar * AS + ak + i] = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Bs[bk * BS + bc + i] = rb[i];
+    __syncthreads();
+    if (k0 + KC < K) gload(k0 + KC);
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const double a = As[(16 * w + fr) * AS + 4 * kk + fk];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(4 * kk + fk) * BS + 16 * n + fr], acc[n], 0, 0, 0);
+    }
+  }
+  // C fragment: column = lane & 15, row = (lane >> 4) + 4 v
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      C[(long)(16 * w + (lane >> 4) + 4 * v) * ldc + 16 * n + (lane & 15)] = (T)(g.alpha * acc[n][v]);
+}
+template <class T>
+static void launch_blockmm_t(hipStream_t s, int nprod, const T *const *A, const int64_t *lda, const T *const *B,
+                             const int64_t *ldb, T *const *C, const int64_t *ldc, const int *K, double alpha,
+                             unsigned nz, long bstride) {
+  if (nprod <= 0) return;
+  BlockMM<T> g;
+  for (int b = 0; b < nprod; ++b) {
+    g.A[b] = A[b];
+    g.B[b] = B[b];
+    g.C[b] = C[b];
+    g.lda[b] = lda[b];
+    g.ldb[b] = ldb[b];
+    g.ldc[b] = ldc[b];
+    g.K[b] = K[b];
+  }
+  g.alpha = alpha;
+  g.bstride = bstride;
+  hipLaunchKernelGGL(blockmm_kernel<T>, dim3(16, (unsigned)nprod, nz), dim3(256), 0, s, g);
+}
+void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
+                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha) {
+  launch_blockmm_t<double>(s, nprod, A, lda, B, ldb, C, ldc, K, alpha, (unsigned)tl_batch.k, tl_batch.stride);
+}
+void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
+                    const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha) {
+  launch_blockmm_t<float>(s, nprod, A, lda, B, ldb, C, ldc, K, alpha, 1u, 0L);
+}
+
 // zero a rows x cols block (cols a multiple of 2, 16-B aligned)
 template <class T>
 __global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long ld, long cols,

@@ -94,7 +94,8 @@ def test_bench_two_ranks_as_the_driver_runs_it():
     d = _one_line(r.stdout)
     assert d["n_gpus"] == 2
     assert d["preflight"]["comm_ranks"] == 2 and d["preflight"]["rccl"] is False
-    assert d["rccl_ranks"] is None  # not an RCCL run: the field is only filled from ncclCommCount
+    assert d["rccl_ranks"] == 0  # not an RCCL run: the field is only filled from ncclCommCount (0, never null)
+    assert d["transport_ok"] is True  # the transport that was asked for (the gloo rehearsal) came up
     assert d["value"] > 0 and "error" not in d
     sh = d["sharded_evaluation"]
     assert "error" not in sh, sh

@@ -395,6 +395,56 @@ def test_absorb_then_produce_and_restore(gpmod):
     assert abs(g2.LML() - g.LML()) <= 1e-9 * abs(g.LML())
 
 
+@pytest.mark.parametrize("n,m,prec", [(700, 33, 64), (2300, 300, 64), (5000, 1100, 64), (2300, 300, 32)])
+def test_produce_through_superpanel_inverses_matches_panel_substitution(gpmod, n, m, prec):
+    """Produce solves V^T = Kstar^T L^-T super-panel by super-panel through T^-1, the inverse of the factor's diagonal
+    block assembled from the 256-block inverses by the first Produce on a factor (api.hip: assemble_tinv; the batched
+    plain products of solve.hip: blockmm_kernel) -- one product per super-panel instead of a solve + update per 256
+    columns (gp/gp.go:337-342 is one SolveTo either way).  Against round 3's panel-by-panel substitution (option
+    produce_tinv = 0) and the oracle; a second Produce reuses the inverses, another blocking (produce_panels) and a new
+    factor rebuild them."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(n + m)
+    D = 3
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(-0.1, 1.1, (m, D))
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    x = np.log([1.3, 0.6, 0.15])
+    g = gpmod.GP(D, simil, noise, X=X, Y=y, precision=prec)
+    g.Observe(x)
+    mu1, s1 = g.Produce(Z)           # assembles T^-1
+    mu2, s2 = g.Produce(Z)           # reuses it
+    np.testing.assert_array_equal(mu1, mu2)
+    np.testing.assert_array_equal(s1, s2)
+    g.set_option("produce_tinv", 0)  # round 3's substitution on the same factor
+    mu0, s0 = g.Produce(Z)
+    tol = 1e-9 if prec == 64 else 2e-3
+    np.testing.assert_allclose(mu1, mu0, rtol=tol, atol=tol)
+    np.testing.assert_allclose(s1, s0, rtol=tol, atol=tol)
+    g.set_option("produce_tinv", 1)
+    for pw, groups in ((1, 1), (3, 4), (8, 2)):
+        g.set_option("produce_panels", pw)
+        g.set_option("produce_groups", groups)
+        mu3, s3 = g.Produce(Z)
+        np.testing.assert_allclose(mu3, mu0, rtol=tol, atol=tol)
+        np.testing.assert_allclose(s3, s0, rtol=tol, atol=tol)
+    if prec == 64:
+        o = FastOracle(D, simil, noise)
+        o.set_data(X, y)
+        o.Observe(x)
+        mu_o, s_o = o.Produce(Z)
+        np.testing.assert_allclose(mu1, mu_o, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(s1, s_o, rtol=1e-6, atol=1e-8)
+        x2 = np.log([0.9, 0.45, 0.2])  # a new factor: the inverses of the old one must not be used
+        g.Observe(x2)
+        o.Observe(x2)
+        mu4, s4 = g.Produce(Z)
+        mu_o, s_o = o.Produce(Z)
+        np.testing.assert_allclose(mu4, mu_o, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(s4, s_o, rtol=1e-6, atol=1e-8)
+    g.close()
+
+
 def test_not_positive_definite(gpmod):
     """Duplicate inputs with zero noise: Factorize fails (gp/gp.go:228-230)."""
     X = np.array([[0.0], [0.0], [1.0]])
