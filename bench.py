@@ -678,6 +678,27 @@ def main():
                 "evals_per_s": steps * cps / tg, "ms_per_step": tg / steps * 1e3,
                 "note": "the timed steps repeated with profiling events off: the launch sequence of a step "
                         "is one captured hipGraph (linear; N <= 1024)"}
+        if cps > 1 and 1024 < N <= 8192:
+            # the same steps replayed from an EXPLICITLY built hipGraph (option graph = 2: one node per launch / copy,
+            # the sweep's cross-stream dependencies as edges, no stream capture -- graphrec.h).  Reported, not used for
+            # `value`: this runtime executes the graph's parallel branches no faster than their serialisation.
+            ref_l, ref_g = step(3)
+            g.set_option("graph", 2)
+            step(0); step(1); step(2)
+            got_l, got_g = step(3)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for kk in range(steps):
+                step(2 + kk)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            nodes, refused = g.graph_info()
+            g.set_option("graph", 1)
+            out["hipgraph_replay"] = {
+                "evals_per_s": steps * cps / tg, "ms_per_step": tg / steps * 1e3, "nodes": nodes, "refused_by_runtime": refused,
+                "bit_identical_to_stream_path": bool(ref_l == got_l and np.array_equal(ref_g, got_g)),
+                "note": "explicitly built hipGraph of one step (hipGraphAddKernelNode / MemcpyNode / MemsetNode with "
+                        "explicit dependencies); `value` above is the stream path, which is faster on this runtime"}
         if cps > 1:
             # the same workload one candidate at a time (the latency-bound chain `value` amortises)
             g.Observe(wl.log_theta(0)); g.Gradient()

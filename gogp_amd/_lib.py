@@ -43,6 +43,7 @@ SYMBOLS = [
     ("gogp_destroy", None, [_h]),
     ("gogp_last_error", ctypes.c_char_p, [_h]),
     ("gogp_notpd_index", _i64, [_h]),
+    ("gogp_graph_info", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
     ("gogp_set_data", ctypes.c_int, [_h, _dp, _dp, _i64]),
     ("gogp_set_data_device", ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_void_p, _i64]),
     ("gogp_absorb", ctypes.c_int, [_h, _dp, _dp]),

@@ -433,22 +433,22 @@ int gogp_upload_params(gogp_handle *h) {
 static hipError_t cand_memset(gogp_handle *h, void *dst, size_t bytes, hipStream_t s) {
   hipError_t e = hipSuccess;
   for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
-    e = hipMemsetAsync((char *)dst + (size_t)c * h->cand_stride, 0, bytes, s);
+    e = gogp::rec_memset_async((char *)dst + (size_t)c * h->cand_stride, 0, bytes, s);
   return e;
 }
 // shared source (y) into every candidate's copy
 static hipError_t cand_copy_in(gogp_handle *h, void *dst, const void *src, size_t bytes, hipStream_t s) {
   hipError_t e = hipSuccess;
   for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
-    e = hipMemcpyAsync((char *)dst + (size_t)c * h->cand_stride, src, bytes, hipMemcpyDeviceToDevice, s);
+    e = gogp::rec_memcpy_async((char *)dst + (size_t)c * h->cand_stride, src, bytes, hipMemcpyDeviceToDevice, s);
   return e;
 }
 // device results of every candidate into its row of the pinned staging block (rows of NACC + 16 doubles)
 static hipError_t cand_d2h(gogp_handle *h, double *hdst, const void *dsrc, size_t bytes, hipStream_t s) {
   hipError_t e = hipSuccess;
   for (int c = 0; c < h->batch_k && e == hipSuccess; ++c)
-    e = hipMemcpyAsync(hdst + (size_t)c * (NACC + 16), (const char *)dsrc + (size_t)c * h->cand_stride, bytes,
-                       hipMemcpyDeviceToHost, s);
+    e = gogp::rec_memcpy_async(hdst + (size_t)c * (NACC + 16), (const char *)dsrc + (size_t)c * h->cand_stride, bytes,
+                               hipMemcpyDeviceToHost, s);
   return e;
 }
 
@@ -470,7 +470,7 @@ static int ensure_y(gogp_handle *h) {
 // refined alpha, [8] first failing pivot + 1).
 struct FactorResult {
   int rc = GOGP_OK;
-  double lml = 0.0, cond_lb = 1.0;
+  double lml = 0.0, cond_lb = 1.0, yta = 0.0;
   int64_t notpd = -1;
   std::string msg;
 };
@@ -489,6 +489,7 @@ static FactorResult judge_scalars(const gogp_handle *h, const double *hs, bool f
   // fp32 path: the log-determinant summed from the fp64 diagonal-block factors
   const double logdet = fp32 ? hs[5] : hs[0];
   const double ztz = refine ? hs[6] : hs[1];  // y^T alpha (refined) / z^T z
+  r.yta = ztz;
   // gp/gp.go:244-253
   r.lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * ztz;
   // gonum's Cholesky solves return a Condition error when its condition estimate exceeds
@@ -680,7 +681,7 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
     // The next super-step's columns stay on the CHAIN stream (as in the Cholesky sweep: no
     // event hop on the chain); they were last touched by the previous super-step's bulk update.
     if (P0 > 0 && st != s2)
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * prevP0 + 3), 0);
+      (void)gogp::rec_stream_wait(st, ev(h, EV_BASE + 4 * prevP0 + 3));
     // The super-panel of Y is upper triangular in its own block rows C0 .. CE: tile row C0/128 + i only sums
     // k >= i * 128 (krag0) -- half of the K range of those rows, 0.1 TFLOP of an N = 16384 evaluation that is
     // no longer launched (4.58 -> 4.50 TFLOP; the evaluation's time does not move: 71.43 -> 71.35 ms, the
@@ -695,7 +696,7 @@ static void trtri_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
       launch_gemm_nt(s2, GEMM_RECT, mr, nt - ntn, Kw, -1.0, Y + C0, ld, L + C3 * ld + C0, ld, 1.0,
                       R + C3, ld, pf, &gbulk);
     }
-    (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 3), s2);  // bulk R update of super-step P0 done
+    (void)gogp::rec_event_record(ev(h, EV_BASE + 4 * P0 + 3), s2);  // bulk R update of super-step P0 done
   }
 }
 
@@ -710,14 +711,14 @@ static int factorize_t(gogp_handle *h, bool eager) {
   hipStream_t st = h->st, s2 = h->s2;
   if (h->trtri_pending) {
     // a previous Observe left its triangular inverse running: it reads L / Dinv
-    (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
-    (void)hipStreamWaitEvent(sp, ev(h, EV_TRTRI), 0);
+    (void)gogp::rec_stream_wait(s, ev(h, EV_TRTRI));
+    (void)gogp::rec_stream_wait(sp, ev(h, EV_TRTRI));
     h->trtri_pending = false;
   }
   if (h->kinv_pending) {
     // ... and K^-1 accumulating in bufA
-    (void)hipStreamWaitEvent(s, ev(h, EV_KINV), 0);
-    (void)hipStreamWaitEvent(sp, ev(h, EV_KINV), 0);
+    (void)gogp::rec_stream_wait(s, ev(h, EV_KINV));
+    (void)gogp::rec_stream_wait(sp, ev(h, EV_KINV));
     h->kinv_pending = false;
   }
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
@@ -744,12 +745,12 @@ static int factorize_t(gogp_handle *h, bool eager) {
     launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, reinterpret_cast<T *>(h->bufA), ld,
                             (int64_t)superpanel_width(h, (int)(npad / PANEL), 0) * PANEL);
   }
-  (void)hipEventRecord(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
+  (void)gogp::rec_event_record(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
                                             // is NOT implied: consumers of columns < 512 are on sp)
   if (eager) {
     // R := 0 on the strictly upper block triangle (after whatever used bufA last)
-    (void)hipStreamWaitEvent(s2, ev(h, EV_GRAM), 0);
-    (void)hipStreamWaitEvent(st, ev(h, EV_GRAM), 0);
+    (void)gogp::rec_stream_wait(s2, ev(h, EV_GRAM));
+    (void)gogp::rec_stream_wait(st, ev(h, EV_GRAM));
     launch_zero_upper_blocks(s2, reinterpret_cast<T *>(h->bufA), ld, npad);
     order(h, EV_INIT, s2, st);  // st also writes R (updates inside a super-panel)
   }
@@ -808,7 +809,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
       }
     }
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
-    if (sz != sp) (void)hipStreamWaitEvent(sz, ev(h, EV_BASE + 4 * P0), 0);
+    if (sz != sp) (void)gogp::rec_stream_wait(sz, ev(h, EV_BASE + 4 * P0));
 
     for (int q = 0; q < nsub; ++q)
       launch_trsv_fwd_step(sz, L, ld, Dinv, P0 + q, npanel, h->w, h->z);
@@ -822,7 +823,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
       // never crosses streams (two event hops of ~15 us per super-panel otherwise).  They
       // only wait for the previous super-panel's bulk update of these columns, which in
       // steady state finished long ago.
-      (void)hipStreamWaitEvent(sp, ev(h, P0 > 0 ? EV_BASE + 4 * prevP0 + 1 : EV_GRAM), 0);
+      (void)gogp::rec_stream_wait(sp, ev(h, P0 > 0 ? EV_BASE + 4 * prevP0 + 1 : EV_GRAM));
       // ONE trapezoid launch for all of them (rows CE.., columns CE .. CE + ntn*128, the
       // strictly upper 256-blocks -- R of the triangular inverse -- skipped): separate
       // launches would run one after the other on this in-order stream
@@ -836,11 +837,11 @@ static int factorize_t(gogp_handle *h, bool eager) {
         launch_gemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
       }
-      (void)hipEventRecord(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
+      (void)gogp::rec_event_record(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
     }
     // ---- fused sweep: the same super-step of the triangular inverse right behind ----------
     if (eager) {
-      (void)hipStreamWaitEvent(st, ev(h, EV_BASE + 4 * P0), 0);
+      (void)gogp::rec_stream_wait(st, ev(h, EV_BASE + 4 * P0));
       trtri_superstep<T>(h, P0, nsub, prevP0, next_nsub, st, s2);
       if (fuse_kinv) {
         // ---- and K^-1 = Y Y^T = sum over the column panels of Y, right behind: the rank-(nsub*256)
@@ -848,7 +849,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
         // C0.. are new: overwritten).  That corner of bufA is dead (panels < CE of L are final) and
         // disjoint from R.  The updates wait for nothing but their panel of Y and grow towards the
         // end of the sweep, where the two chains leave most of the GPU idle: lowest priority.
-        (void)hipStreamWaitEvent(h->sk, ev(h, EV_BASE + 4 * P0 + 2), 0);
+        (void)gogp::rec_stream_wait(h->sk, ev(h, EV_BASE + 4 * P0 + 2));
         GemmGrid gk;
         gk.new_row0 = (int)(C0 / TILE);
         if (h->krag) gk.krag0 = (int)(C0 / TILE);
@@ -859,14 +860,14 @@ static int factorize_t(gogp_handle *h, bool eager) {
     }
   }
   if (fuse_kinv) {
-    (void)hipEventRecord(ev(h, EV_KINV), h->sk);
+    (void)gogp::rec_event_record(ev(h, EV_KINV), h->sk);
     h->kinv_pending = true;
   }
 
   h->ydone_valid = false;
   if (eager) {
-    (void)hipEventRecord(ev(h, EV_TRTRI), st);
-    (void)hipEventRecord(ev(h, EV_YDONE), st);  // K^-1 = Y Y^T may start here; alpha = Y z (below) runs beside it
+    (void)gogp::rec_event_record(ev(h, EV_TRTRI), st);
+    (void)gogp::rec_event_record(ev(h, EV_YDONE), st);  // K^-1 = Y Y^T may start here; alpha = Y z (below) runs beside it
     h->ydone_valid = true;
     h->trtri_done = true;
     h->trtri_pending = true;
@@ -880,7 +881,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     // read back from its rounded copy): r = y - K alpha, alpha += K~^-1 r.  The quadratic term of
     // the LML is y^T alpha of the refined alpha (fp64).  All of it on the chain stream, which is
     // idle after the last panel; the triangular inverse keeps running on its own streams.
-    if (sz != sp) (void)hipStreamWaitEvent(sp, ev(h, EV_FWD), 0);
+    if (sz != sp) (void)gogp::rec_stream_wait(sp, ev(h, EV_FWD));
     HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
     for (int b = npanel - 1; b >= 0; --b) launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->w, h->alpha);
     const size_t vb = (size_t)npad * sizeof(double);
@@ -898,21 +899,21 @@ static int factorize_t(gogp_handle *h, bool eager) {
   HIPCHK(h, cand_d2h(h, h->hscal, h->scalars, 7 * sizeof(double), s));
   HIPCHK(h, cand_d2h(h, h->hscal + 8, h->info, sizeof(long long), s));
   if (refine) {
-    if (eager) (void)hipEventRecord(ev(h, EV_TRTRI), st);
+    if (eager) (void)gogp::rec_event_record(ev(h, EV_TRTRI), st);
   } else if (eager) {
     // alpha = K^-1 y = Y (L^-1 y) = Y z: one bandwidth-bound pass over Y once the
     // triangular inverse is complete (st), instead of 64 dependent substitution steps
-    (void)hipStreamWaitEvent(st, ev(h, EV_FWD), 0);
+    (void)gogp::rec_stream_wait(st, ev(h, EV_FWD));
     launch_alpha_from_y(st, reinterpret_cast<const T *>(h->bufY), ld, h->z, npad, h->alpha);
-    (void)hipEventRecord(ev(h, EV_ALPHA), st);
-    (void)hipEventRecord(ev(h, EV_TRTRI), st);
+    (void)gogp::rec_event_record(ev(h, EV_ALPHA), st);
+    (void)gogp::rec_event_record(ev(h, EV_TRTRI), st);
   } else {
     // backward substitution alpha = L^-T z on the panel stream: not needed for LML
-    if (sz != sp) (void)hipStreamWaitEvent(sp, ev(h, EV_FWD), 0);
+    if (sz != sp) (void)gogp::rec_stream_wait(sp, ev(h, EV_FWD));
     HIPCHK(h, hipMemcpyAsync(h->w, h->z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, sp));
     for (int b = npanel - 1; b >= 0; --b)
       launch_trsv_bwd_step(sp, L, ld, Dinv, b, npanel, h->w, h->alpha);
-    (void)hipEventRecord(ev(h, EV_ALPHA), sp);
+    (void)gogp::rec_event_record(ev(h, EV_ALPHA), sp);
   }
   h->alpha_pending = true;
   if (h->batch_mode) {  // the caller synchronises and judges every candidate from its own row of hscal
@@ -937,6 +938,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     return GOGP_ENOTPD;
   }
   h->lml = fr.lml;
+  h->yta = fr.yta;
   h->factored = true;
   h->have_alpha = true;
   h->cond_lb = fr.cond_lb;
@@ -953,7 +955,7 @@ static int factorize(gogp_handle *h, bool eager) {
 static int ensure_alpha(gogp_handle *h) {
   if (!h->factored || !h->have_alpha) return fail(h, GOGP_ESTATE, "no factorisation");
   if (h->alpha_pending) {
-    HIPCHK(h, hipStreamWaitEvent(h->s, ev(h, EV_ALPHA), 0));
+    HIPCHK(h, gogp::rec_stream_wait(h->s, ev(h, EV_ALPHA)));
     h->alpha_pending = false;
   }
   return GOGP_OK;
@@ -1060,8 +1062,8 @@ static int compute_kinv_t(gogp_handle *h) {
   GemmProfile *pf = &h->prof;
   if (h->kinv_pending) {
     // the fused sweep accumulated K^-1 behind the triangular inverse (factorize_t): nothing to launch
-    (void)hipStreamWaitEvent(s, ev(h, EV_KINV), 0);
-    if (h->trtri_pending) (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+    (void)gogp::rec_stream_wait(s, ev(h, EV_KINV));
+    if (h->trtri_pending) (void)gogp::rec_stream_wait(s, ev(h, EV_TRTRI));
     h->kinv_pending = h->trtri_pending = false;
     h->have_kinv = true;
     return GOGP_OK;
@@ -1084,13 +1086,13 @@ static int compute_kinv_t(gogp_handle *h) {
   } else if (h->trtri_pending) {
     // Y final is enough to start; what the inverse's chain stream still does behind it (alpha = Y z, a
     // bandwidth-bound 0.2 ms at N = 16384) reads Y and writes alpha only
-    (void)hipStreamWaitEvent(s, ev(h, h->ydone_valid ? EV_YDONE : EV_TRTRI), 0);
+    (void)gogp::rec_stream_wait(s, ev(h, h->ydone_valid ? EV_YDONE : EV_TRTRI));
   }
   // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
   launch_gemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, reinterpret_cast<const T *>(h->bufY), ld,
                  reinterpret_cast<const T *>(h->bufY), ld, 0.0, reinterpret_cast<T *>(h->bufA), ld, pf);
   // whatever follows on s is ordered behind ALL of the inverse's chain stream
-  if (h->trtri_pending && h->ydone_valid) (void)hipStreamWaitEvent(s, ev(h, EV_TRTRI), 0);
+  if (h->trtri_pending && h->ydone_valid) (void)gogp::rec_stream_wait(s, ev(h, EV_TRTRI));
   h->trtri_pending = false;
   h->have_kinv = true;
   return GOGP_OK;
@@ -1117,6 +1119,21 @@ static void assemble_gradient(const gogp_handle *h, const double *a, double dnoi
     if (T.kind == GOGP_K_PERIODIC) out[T.period_idx] += 0.5 * a[3 * t + 2];
   }
   if (h->nn > 0) out[h->ns] = 0.5 * a[ACC_TRACE] * dnoise;
+}
+
+// fp32 path: two slot sums of the gradient reduction cancel badly when K is ill-conditioned -- the entries of the fp32
+// K^-1 are of the size 1 / noise and the sums over W = alpha alpha^T - K^-1 are what is left of them -- and both have
+// closed forms that never touch the off-diagonal of K^-1:
+//   trace slot     tr(W) = |alpha|^2 - |Y|_F^2                    (fp64 sums over Y = L^-T, launch_trace_from_y)
+//   scale slot     sum_ij W_ij c k_ij = tr(W (K - v I)) = (y^T alpha - n) - v tr(W)     (K alpha = y holds for the
+//                  refined alpha; v: the noise variance on the diagonal) -- one radial term with an output scale.
+// Measured on the stress case of round 3 (Matern-3/2, N = 1721, D = 2, gradient error 3.6e-3 of its largest
+// component, all of it in the scale slot): tests/test_gpu_parity.py::test_fp32_gradient_ill_conditioned_case.
+static void fp32_gradient_identities(const gogp_handle *h, double *a, double trace_w) {
+  const gogp_desc &d = h->desc;
+  a[ACC_TRACE] = trace_w;
+  if (d.nterms == 1 && d.terms[0].scale_idx >= 0)
+    a[0] = (h->yta - (double)h->n) - h->hostP->noise_var * trace_w;
 }
 
 extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
@@ -1150,8 +1167,16 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
                            h->npad, h->gpart, h->gout, h->radial1, h->ard_mfma_min);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), s));
+    h->hscal[9] = NAN;
+    if (h->prec == 32 && h->trace_fp64 && h->bufY && h->trtri_done) {
+      // tr(alpha alpha^T - K^-1) in fp64 from Y itself (solve.hip: launch_trace_from_y); rw / scalars[7]: free here
+      launch_trace_from_y(s, reinterpret_cast<const float *>(h->bufY), h->npad, h->n, h->npad, h->alpha, h->rw,
+                          h->scalars + 7);
+      HIPCHK(h, hipMemcpyAsync(h->hscal + 9, h->scalars + 7, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
+    if (h->prec == 32 && std::isfinite(h->hscal[9])) fp32_gradient_identities(h, h->hscal + 16, h->hscal[9]);
   }
   if (!h->grad_valid) {
     h->grad_cache.assign(h->P, 0.0);
@@ -1215,7 +1240,8 @@ extern "C" int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double
 // competing for the hardware queues.  Each candidate works in its own arena slot; the handle's own
 // buffers and state (a previous Observe / Absorb) are left untouched.
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr int64_t GRAPH_MAX_NPAD = 1024;  // option "graph": linear graphs only (see the capture below)
+constexpr int64_t GRAPH_MAX_NPAD = 1024;           // option "graph" = 1: one chain in enqueue order
+constexpr int64_t GRAPH_EXPLICIT_MAX_NPAD = 8192;  // option "graph" = 2: the sweep's dependencies as edges
 
 struct CandLayout {
   size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, total;
@@ -1352,8 +1378,8 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   // the whole launch sequence: parameter upload, fused sweep, K^-1, gradient sums, results to the host
   auto enqueue = [&]() -> int {
     for (int c = 0; c < k; ++c)
-      HIPCHK(h, hipMemcpyAsync((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c, sizeof(DevParams),
-                               hipMemcpyHostToDevice, h->s));
+      HIPCHK(h, gogp::rec_memcpy_async((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c,
+                                       sizeof(DevParams), hipMemcpyHostToDevice, h->s));
     int r = factorize_t<double>(h, true);
     if (r != GOGP_OK) return r;
     r = compute_kinv_t<double>(h);
@@ -1373,10 +1399,18 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   };
   auto run = [&]() -> int {
     int r = GOGP_OK;
-    const bool graph = h->use_graph && !h->prof.on && h->npad <= GRAPH_MAX_NPAD;
+    // option "graph": the launch sequence replayed from a hipGraph.  1 (default): one chain, captured with the work
+    // streams aliased to one capture stream, up to npad = 1024 -- where an evaluation is a single dependent chain
+    // anyway and the launch path is the cost.  2: an EXPLICITLY built graph (graphrec.h: one node per launch / copy,
+    // the sweep's real cross-stream dependencies as edges, no stream captured), up to npad = 8192 -- bit-identical to
+    // the streams, but this runtime executes parallel branches no faster than their serialisation (N = 4096: 6.1 ms
+    // against 3.7 ms on the streams), so it is not the default.  0: streams.
+    const bool dag = h->use_graph == 2;
+    const bool graph = h->use_graph && !h->prof.on && !h->graph_failed &&
+                       h->npad <= (dag ? GRAPH_EXPLICIT_MAX_NPAD : GRAPH_MAX_NPAD);
     auto &key = h->cand_graph_key;
     auto same = [&](const decltype(h->cand_graph_key) &q) {
-      return q.k == k && q.n == h->n && q.superpanel == h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining && q.arena == h->cand_arena &&
+      return q.k == k && q.n == h->n && q.superpanel == h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 4096 * h->use_graph && q.arena == h->cand_arena &&
              q.stride == h->cand_stride && q.cap_npad == h->cand_cap_npad && q.kinv_fused == h->kinv_fused &&
              q.dX == h->dX && q.dy == h->dy && q.hostP == h->cand_hostP && q.hscal == h->cand_hscal;
     };
@@ -1386,7 +1420,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     const bool seen = graph && same(h->cand_seen_key);
     h->cand_seen_key.k = k;
     h->cand_seen_key.n = h->n;
-    h->cand_seen_key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
+    h->cand_seen_key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 4096 * h->use_graph;
     h->cand_seen_key.arena = h->cand_arena;
     h->cand_seen_key.stride = h->cand_stride;
     h->cand_seen_key.cap_npad = h->cand_cap_npad;
@@ -1396,7 +1430,46 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     h->cand_seen_key.hostP = h->cand_hostP;
     h->cand_seen_key.hscal = h->cand_hscal;
     if (hit || seen) {
-      if (!hit) {
+      if (!hit && dag) {
+        // No stream is captured: the launch sequence is replayed into a recorder that adds one node per launch /
+        // copy with explicit dependencies (graphrec.h), so hipStreamEndCapture's trouble with the sweep's fork / join
+        // pattern (round 2) never arises.
+        drop_cand_graph(h);
+        HIPCHK(h, graph_stream(h));
+        gogp::GraphRec rec;
+        HIPCHK(h, hipGraphCreate(&rec.graph, 0));
+        gogp::tl_rec = &rec;
+        r = enqueue();
+        gogp::tl_rec = nullptr;
+        hipError_t ei = (r == GOGP_OK) ? rec.err : hipSuccess;
+        if (r == GOGP_OK && ei == hipSuccess) ei = hipGraphInstantiate(&h->cand_graph, rec.graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(rec.graph);
+        if (r != GOGP_OK) return r;
+        if (ei != hipSuccess) {
+          // the runtime refused the graph: remember it, say why, and evaluate on the streams (never retried)
+          (void)hipGetLastError();
+          h->cand_graph = nullptr;
+          h->graph_failed = true;
+          h->graph_note = std::string("hipGraph not usable (") + hipGetErrorString(ei) + "): stream path";
+          r = enqueue();
+          if (r != GOGP_OK) return r;
+          for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
+          HIPCHK(h, hipGetLastError());
+          return GOGP_OK;
+        }
+        h->graph_nodes = rec.nodes;
+        key.k = k;
+        key.n = h->n;
+        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 4096 * h->use_graph;
+        key.arena = h->cand_arena;
+        key.stride = h->cand_stride;
+        key.cap_npad = h->cand_cap_npad;
+        key.kinv_fused = h->kinv_fused;
+        key.dX = h->dX;
+        key.dy = h->dy;
+        key.hostP = h->cand_hostP;
+        key.hscal = h->cand_hscal;
+      } else if (!hit) {
         drop_cand_graph(h);
         hipGraph_t gr = nullptr;
         // Captured on ONE stream (the five work streams aliased to it for the duration): a linear
@@ -1428,7 +1501,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         HIPCHK(h, ei);
         key.k = k;
         key.n = h->n;
-        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining;
+        key.superpanel = h->superpanel + 16 * h->superpanel_head + 256 * h->head_remaining + 4096 * h->use_graph;
         key.arena = h->cand_arena;
         key.stride = h->cand_stride;
         key.cap_npad = h->cand_cap_npad;
@@ -1513,6 +1586,13 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   return first;
 }
 
+extern "C" int gogp_graph_info(const gogp_handle *h, int64_t *nodes, int *refused) {
+  if (!h) return GOGP_EARG;
+  if (nodes) *nodes = h->cand_graph ? h->graph_nodes : 0;
+  if (refused) *refused = h->graph_failed ? 1 : 0;
+  return GOGP_OK;
+}
+
 // ---- produce ----------------------------------------------------------------------------------
 static int ensure_m(gogp_handle *h, int64_t m, int64_t mpad) {
   if (m > h->cap_m || mpad * h->npad > h->cap_mp_npad || !h->dZ) {
@@ -1567,7 +1647,7 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
     for (int P0 = 0, nsub = 0; P0 < npanel; P0 += nsub) {
       nsub = std::min(pw, npanel - P0);
       assemble_tinv<T>(h, h->sk, P0, nsub);
-      (void)hipEventRecord(ev(h, evt0 + (size_t)P0), h->sk);
+      (void)gogp::rec_event_record(ev(h, evt0 + (size_t)P0), h->sk);
     }
     h->tinv_valid = true;
     h->tinv_sig = tinv_signature(h);
@@ -1589,7 +1669,7 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
       gtri.ktri = h->ktri;
       gtri.small_below = gup.small_below = h->produce_small_below;
       if (use_tinv) {
-        if (assemble) (void)hipStreamWaitEvent(sg, ev(h, evt0 + (size_t)P0), 0);
+        if (assemble) (void)gogp::rec_stream_wait(sg, ev(h, evt0 + (size_t)P0));
         // the whole super-panel at once: V[:, C0:CE] = R[:, C0:CE] T^-T with the assembled inverse of the factor's
         // diagonal block -- the same flops as the panel-by-panel substitution (T^-1 is lower triangular: ktri), 2
         // dependent launches per super-panel instead of 2 per 256 columns
@@ -1919,6 +1999,10 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     h->produce_groups = (int)value;
     return GOGP_OK;
   }
+  if (strcmp(name, "trace_fp64") == 0) {  // fp32 path: trace / scale components of the gradient by their closed forms
+    h->trace_fp64 = value != 0;
+    return GOGP_OK;
+  }
   if (strcmp(name, "krag") == 0) {  // the inverse's updates skip the zero triangle of a super-panel of Y
     h->krag = value != 0;
     return GOGP_OK;
@@ -1986,9 +2070,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     HIPCHK(h, apply_inv_prio(h));
     return GOGP_OK;
   }
-  if (strcmp(name, "graph") == 0) {  // candidates: replay a captured hipGraph instead of re-enqueueing
-    h->use_graph = value != 0;
-    if (!h->use_graph) drop_cand_graph(h);
+  if (strcmp(name, "graph") == 0) {  // candidates: hipGraph replay -- 1 a chain (N <= 1024), 2 the real DAG (N <= 8192), 0 streams
+    if (value < 0 || value > 2) return fail(h, GOGP_EARG, "graph must be 0..2");
+    h->use_graph = (int)value;
+    h->graph_failed = false;
+    drop_cand_graph(h);
     return GOGP_OK;
   }
   if (strcmp(name, "refine_steps") == 0) {

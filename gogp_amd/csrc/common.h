@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/gogp_hip.h"
+#include "graphrec.h"
 
 namespace gogp {
 
@@ -268,6 +269,9 @@ void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int6
                     const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha);
 void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
                     const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha);
+// fp32 path: out[0] = sum_{i<n} alpha_i^2 - |Y|_F^2 (= tr(alpha alpha^T - K^-1)) in fp64 from Y = L^-T; part: n doubles
+void launch_trace_from_y(hipStream_t s, const float *Y, int64_t ld, int64_t n, int64_t npad, const double *alpha,
+                         double *part, double *out);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b

@@ -424,7 +424,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     if (e0)                                                                               \
       hipExtLaunchKernelGGL((__VA_ARGS__), (GRID), (BLOCK), 0, s, e0, e1, 0, g);           \
     else                                                                                  \
-      hipLaunchKernelGGL((__VA_ARGS__), (GRID), (BLOCK), 0, s, g);                         \
+      GOGP_KLAUNCH((__VA_ARGS__), (GRID), (BLOCK), 0, s, g);                         \
   } while (0)
   // Small launches (the skinny GEMMs of the panel chain) use 64x64 tiles: 4x the
   // workgroups and a quarter of the per-tile latency.  LAUUM keeps 128 (its K

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
 
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
-  hipLaunchKernelGGL((diag256_kernel<true, false, 256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s,
+  GOGP_KLAUNCH((diag256_kernel<true, false, 256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s,
                      A, (long)ld, Lout, (long)ldl, Dinv, (long)row0, (long)nvalid, info,
                      (unsigned long long *)nullptr, gogp::tl_batch.stride);
 }
@@ -621,21 +621,21 @@ void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, in
 #ifndef GOGP_BUILD_TESTHOOKS
 void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                           double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
-  hipLaunchKernelGGL((diag256_kernel<true, false, 512>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
+  GOGP_KLAUNCH((diag256_kernel<true, false, 512>), dim3(1), dim3(NT), 0, s, A, (long)ld, Lout,
                      (long)ldl, Dinv, (long)row0, (long)nvalid, info,
                      (unsigned long long *)nullptr, 0L);
 }
 #endif
 
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv) {
-  hipLaunchKernelGGL((diag256_kernel<false, false, 256>), dim3(1), dim3(NT), 0, s, L, (long)ld,
+  GOGP_KLAUNCH((diag256_kernel<false, false, 256>), dim3(1), dim3(NT), 0, s, L, (long)ld,
                      (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
                      (unsigned long long *)nullptr, 0L);
 }
 
 #ifndef GOGP_BUILD_TESTHOOKS
 void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv) {
-  hipLaunchKernelGGL((diag256_kernel<false, false, 512>), dim3(1), dim3(NT), 0, s, L, (long)ld,
+  GOGP_KLAUNCH((diag256_kernel<false, false, 512>), dim3(1), dim3(NT), 0, s, L, (long)ld,
                      (double *)nullptr, 0L, Dinv, 0L, 0L, (long long *)nullptr,
                      (unsigned long long *)nullptr, 0L);
 }
@@ -645,7 +645,7 @@ void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, d
 // diagnostic: run the stamped build once on a device-resident 256x256 block
 void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
                             long long *info, unsigned long long *stamps) {
-  hipLaunchKernelGGL((diag256_kernel<true, true, 256>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
+  GOGP_KLAUNCH((diag256_kernel<true, true, 256>), dim3(1), dim3(NT), 0, s, A, 256L, Lout, 256L,
                      Dinv, 0L, 256L, info, stamps, 0L);
 }
 #endif

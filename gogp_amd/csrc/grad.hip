@@ -240,11 +240,11 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
 #define GOGP_LAUNCH_GR(AD, A0)                                                                    \
   do {                                                                                            \
     if (radial1)                                                                                  \
-      hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
+      GOGP_KLAUNCH((grad_reduce_kernel<AD, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
                          alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
                          tl_batch.stride);                                                        \
     else                                                                                          \
-      hipLaunchKernelGGL((grad_reduce_kernel<AD, false, KT, false>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
+      GOGP_KLAUNCH((grad_reduce_kernel<AD, false, KT, false>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
                          alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
                          tl_batch.stride);                                                        \
   } while (0)
@@ -260,19 +260,19 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
     for (int a0 = 0; a0 < ard_dims; a0 += 32) {
       const int left = ard_dims - a0;
       if (left <= 8)
-        hipLaunchKernelGGL((grad_reduce_kernel<8, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+        GOGP_KLAUNCH((grad_reduce_kernel<8, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
                            alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
       else if (left <= 16)
-        hipLaunchKernelGGL((grad_reduce_kernel<16, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+        GOGP_KLAUNCH((grad_reduce_kernel<16, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
                            alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
       else
-        hipLaunchKernelGGL((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
+        GOGP_KLAUNCH((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
                            alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
     }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
 #undef GOGP_LAUNCH_GR
-  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC, 1, nz), dim3(256), 0, s, partials, blocks, out, tl_batch.stride);
+  GOGP_KLAUNCH(grad_final_kernel, dim3(NACC, 1, nz), dim3(256), 0, s, partials, blocks, out, tl_batch.stride);
 }
 void launch_grad_reduce(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                         const double *X, const double *alpha, const double *Kinv, int64_t ld,
@@ -302,10 +302,10 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
   do {                                                                                            \
     if (radial1)                                                                                  \
-      hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+      GOGP_KLAUNCH((grad_reduce_kernel<AD, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                          Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
     else                                                                                          \
-      hipLaunchKernelGGL((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
+      GOGP_KLAUNCH((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
                          Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
   } while (0)
   if (radial1 && ard_dims > 0 && ard_dims >= mfma_min)
@@ -316,19 +316,19 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
     for (int a0 = 0; a0 < ard_dims; a0 += 32) {
       const int left = ard_dims - a0;
       if (left <= 8)
-        hipLaunchKernelGGL((grad_reduce_kernel<8, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+        GOGP_KLAUNCH((grad_reduce_kernel<8, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
                            Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
       else if (left <= 16)
-        hipLaunchKernelGGL((grad_reduce_kernel<16, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+        GOGP_KLAUNCH((grad_reduce_kernel<16, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
                            Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
       else
-        hipLaunchKernelGGL((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
+        GOGP_KLAUNCH((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
                            Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
     }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);
 #undef GOGP_LAUNCH_GRL
-  hipLaunchKernelGGL(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out, 0L);
+  GOGP_KLAUNCH(grad_final_kernel, dim3(NACC), dim3(256), 0, s, partials, blocks, out, 0L);
 }
 void launch_grad_reduce_local(hipStream_t s, const DevParams *p, int ndim, int ard_dims,
                               const double *X, const double *alpha, const double *Kinv, int64_t ld,
@@ -431,7 +431,7 @@ void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
                   const double *alpha, double *Kinv, int64_t ld, int64_t n, int64_t npad,
                   double *gx) {
   const int nt32 = (int)(npad / 32);
-  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, s, Kinv,
+  GOGP_KLAUNCH(mirror_lower_kernel, dim3(nt32 * (nt32 + 1) / 2), dim3(256), 0, s, Kinv,
                      (long)ld, nt32);
   const size_t lds = (size_t)(128 * ndim + 64 * 65 + 64) * sizeof(double);
   const dim3 grid((unsigned)(npad / 64));
@@ -441,7 +441,7 @@ void launch_xgrad(hipStream_t s, const DevParams *p, int ndim, const double *X,
     if (lds > 64 * 1024)                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xgrad_kernel<DM>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-    hipLaunchKernelGGL(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
+    GOGP_KLAUNCH(xgrad_kernel<DM>, grid, dim3(256), lds, s, p, X, alpha, Kinv, (long)ld, \
                        (long)n, (long)npad, gx, D0);                                           \
   } while (0)
   // more than 32 dimensions: passes of 32 (a 64-accumulator instance needs 326 VGPRs, AGPRs included,

@@ -272,7 +272,7 @@ static void launch_ard_mfma_t(hipStream_t s, const DevParams *p, int ndim, const
     if (lds > 65536)                                                                                      \
       (void)hipFuncSetAttribute((const void *)grad_ard_mfma_kernel<DPV, LOCAL, KT>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    hipLaunchKernelGGL((grad_ard_mfma_kernel<DPV, LOCAL, KT>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, alpha, \
+    GOGP_KLAUNCH((grad_ard_mfma_kernel<DPV, LOCAL, KT>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, alpha, \
                        Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, bstride);                 \
   } while (0)
   if (DP == 16) GOGP_LAUNCH_AM(16);

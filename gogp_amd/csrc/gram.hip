@@ -316,12 +316,12 @@ void launch_residual(hipStream_t s, const DevParams *p, int ndim, const double *
   const int tps = (ntile + nslab - 1) / nslab;
   const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
   if (radial1)
-    hipLaunchKernelGGL(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+    GOGP_KLAUNCH(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
                        v, (long)npad, tps, part, 0, ntile);
   else
-    hipLaunchKernelGGL(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+    GOGP_KLAUNCH(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
                        v, (long)npad, tps, part, 0, ntile);
-  hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
+  GOGP_KLAUNCH(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
                      (long)npad, (long)n, y, r);
 }
 
@@ -337,12 +337,12 @@ void launch_kmatvec_share(hipStream_t s, const DevParams *p, int ndim, const dou
   const int tps = std::max(1, (t1 - t0 + nslab - 1) / nslab);
   const size_t lds = (size_t)(128 * ndim + 64 + 256) * sizeof(double);
   if (radial1)
-    hipLaunchKernelGGL(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+    GOGP_KLAUNCH(kmatvec_kernel<true>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
                        v, (long)npad, tps, part, t0, t1);
   else
-    hipLaunchKernelGGL(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
+    GOGP_KLAUNCH(kmatvec_kernel<false>, dim3((unsigned)ntile, (unsigned)nslab), dim3(256), lds, s, p, X, (long)n,
                        v, (long)npad, tps, part, t0, t1);
-  hipLaunchKernelGGL(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
+  GOGP_KLAUNCH(kmatvec_finish_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, part, nslab,
                      (long)npad, (long)n, (const double *)nullptr, out);
 }
 
@@ -362,7 +362,7 @@ static void gram_lower_t(hipStream_t s, const DevParams *p, int ndim, const doub
   const int nt = (int)(npad / 64);
   const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
+  GOGP_KLAUNCH((gram_kernel<false, T>), dim3(ntiles), dim3(256), lds, s, p, X, (long)n, X,
                      (long)n, K, (long)ld, nt, 0, 0, 0L);
 }
 void launch_gram_lower(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -382,11 +382,11 @@ static void gram_lower_split_t(hipStream_t s_first, hipStream_t s_rest, const De
   if (w > nt) w = nt;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
   const unsigned nz = (unsigned)tl_batch.k;
-  hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nt * w, 1, nz), dim3(256), lds, s_first, p, X, (long)n, X,
+  GOGP_KLAUNCH((gram_kernel<false, T>), dim3(nt * w, 1, nz), dim3(256), lds, s_first, p, X, (long)n, X,
                      (long)n, K, (long)ld, nt, w, 0, tl_batch.stride);
   const int nr = nt - w;
   if (nr > 0)
-    hipLaunchKernelGGL((gram_kernel<false, T>), dim3(nr * (nr + 1) / 2, 1, nz), dim3(256), lds, s_rest, p, X,
+    GOGP_KLAUNCH((gram_kernel<false, T>), dim3(nr * (nr + 1) / 2, 1, nz), dim3(256), lds, s_rest, p, X,
                        (long)n, X, (long)n, K, (long)ld, nt, 0, w, tl_batch.stride);
 }
 void launch_gram_lower_split(hipStream_t s_first, hipStream_t s_rest, const DevParams *p, int ndim,
@@ -406,7 +406,7 @@ static void gram_local_t(hipStream_t s, const DevParams *p, int ndim, const doub
   const int ntr = (int)(mrows / 64), ntc = (int)(ncols / 64);
   if (ntr <= 0 || ntc <= 0) return;
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL(gram_local_kernel<T>, dim3(ntr * ntc), dim3(256), lds, s, p, X, (long)n, K, (long)ld,
+  GOGP_KLAUNCH(gram_local_kernel<T>, dim3(ntr * ntc), dim3(256), lds, s, p, X, (long)n, K, (long)ld,
                      ntc, map);
 }
 void launch_gram_local(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -423,7 +423,7 @@ static void cross_t(hipStream_t s, const DevParams *p, int ndim, const double *X
                     int64_t npad, const double *Z, int64_t m, int64_t mpad, T *KsT, int64_t ld) {
   const int ntr = (int)(mpad / 64), ntc = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * ndim * sizeof(double);
-  hipLaunchKernelGGL((gram_kernel<true, T>), dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
+  GOGP_KLAUNCH((gram_kernel<true, T>), dim3(ntr * ntc), dim3(256), lds, s, p, Z, (long)m, X,
                      (long)n, KsT, (long)ld, ntc, 0, 0, 0L);
 }
 void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, int64_t n,
@@ -438,7 +438,7 @@ void launch_cross(hipStream_t s, const DevParams *p, int ndim, const double *X, 
 void launch_prior(hipStream_t s, const DevParams *p, const double *Z, int64_t m,
                   double *prior) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(prior_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, p, Z,
+  GOGP_KLAUNCH(prior_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, p, Z,
                      (long)m, prior);
 }
 

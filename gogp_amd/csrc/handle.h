@@ -61,7 +61,10 @@ struct gogp_handle {
   bool batch_mode = false;      // a batched evaluation is being enqueued (also with k = 1)
   // option "graph": the launch sequence of a batched evaluation captured once into a hipGraph and
   // replayed (the parameters change in pinned host memory only)
-  int use_graph = 1;
+  int use_graph = 1;            // 1: explicitly built graph (graphrec.h), 2: linear graph from stream capture, 0: none
+  bool graph_failed = false;    // the runtime refused the explicit graph once: stream path from then on
+  int graph_nodes = 0;          // nodes of the graph in use (diagnostics)
+  std::string graph_note;
   hipGraphExec_t cand_graph = nullptr;
   hipStream_t sg = nullptr;     // capture / replay stream of that graph (created on first use)
   struct {
@@ -115,6 +118,8 @@ struct gogp_handle {
   bool have_data = false, factored = false, have_alpha = false, have_kinv = false;
   bool observed = false, with_obs = false;
   double lml = 0.0;
+  double yta = 0.0;      // y^T alpha of the last factorisation (fp32 path: of the refined alpha)
+  int trace_fp64 = 1;    // fp32 path: tr(alpha alpha^T - K^-1) summed in fp64 from Y, scale component by its identity
   double cond_lb = 1.0;  // (max L_ii / min L_ii)^2 of the last factorisation
   double cond_limit = 1e16;  // gonum's mat.ConditionTolerance
   std::vector<double> grad_cache;
@@ -194,8 +199,8 @@ static inline hipEvent_t ev(gogp_handle *h, size_t i) {
 // enqueued on `from` before it
 static inline void order(gogp_handle *h, size_t i, hipStream_t from, hipStream_t to) {
   hipEvent_t e = ev(h, i);
-  (void)hipEventRecord(e, from);
-  (void)hipStreamWaitEvent(to, e, 0);
+  (void)gogp::rec_event_record(e, from);  // an explicit graph under construction takes these as dependencies (graphrec.h)
+  (void)gogp::rec_stream_wait(to, e);
 }
 
 

@@ -157,25 +157,25 @@ __global__ __launch_bounds__(256) void trsv_bwd_kernel(const T *__restrict__ L, 
 // nb = number of 256-blocks
 void launch_trsv_fwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nb, double *w, double *z) {
-  hipLaunchKernelGGL(trsv_fwd_kernel<double>, dim3(2 + 2 * (nb - b - 1), 1, (unsigned)tl_batch.k), dim3(256), 0,
+  GOGP_KLAUNCH(trsv_fwd_kernel<double>, dim3(2 + 2 * (nb - b - 1), 1, (unsigned)tl_batch.k), dim3(256), 0,
                      s, L, (long)ld, Dinv, b, w, z, tl_batch.stride);
 }
 void launch_trsv_fwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv,
                           int b, int nb, double *w, double *z) {
-  hipLaunchKernelGGL(trsv_fwd_kernel<float>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
+  GOGP_KLAUNCH(trsv_fwd_kernel<float>, dim3(2 + 2 * (nb - b - 1)), dim3(256), 0, s, L, (long)ld,
                      Dinv, b, w, z, 0L);
 }
 
 void launch_trsv_bwd_step(hipStream_t s, const double *L, int64_t ld, const double *Dinv,
                           int b, int nb, double *w, double *alpha) {
   (void)nb;
-  hipLaunchKernelGGL(trsv_bwd_kernel<double>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+  GOGP_KLAUNCH(trsv_bwd_kernel<double>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
                      alpha);
 }
 void launch_trsv_bwd_step(hipStream_t s, const float *L, int64_t ld, const float *Dinv,
                           int b, int nb, double *w, double *alpha) {
   (void)nb;
-  hipLaunchKernelGGL(trsv_bwd_kernel<float>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
+  GOGP_KLAUNCH(trsv_bwd_kernel<float>, dim3(2 + 2 * b), dim3(256), 0, s, L, (long)ld, Dinv, b, w,
                      alpha);
 }
 
@@ -211,13 +211,13 @@ __global__ __launch_bounds__(256) void alpha_from_y_kernel(const T *__restrict__
 void launch_alpha_from_y(hipStream_t s, const double *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha) {
   if (npad <= 0) return;
-  hipLaunchKernelGGL(alpha_from_y_kernel<double>, dim3((unsigned)((npad + 3) / 4), 1, (unsigned)tl_batch.k),
+  GOGP_KLAUNCH(alpha_from_y_kernel<double>, dim3((unsigned)((npad + 3) / 4), 1, (unsigned)tl_batch.k),
                      dim3(256), 0, s, Y, (long)ld, z, (long)npad, alpha, tl_batch.stride);
 }
 void launch_alpha_from_y(hipStream_t s, const float *Y, int64_t ld, const double *z,
                          int64_t npad, double *alpha) {
   if (npad <= 0) return;
-  hipLaunchKernelGGL(alpha_from_y_kernel<float>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
+  GOGP_KLAUNCH(alpha_from_y_kernel<float>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, Y,
                      (long)ld, z, (long)npad, alpha, 0L);
 }
 
@@ -281,12 +281,12 @@ __global__ __launch_bounds__(1024) void lml_scalars_kernel(const T *__restrict__
 
 void launch_lml_scalars(hipStream_t s, const double *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars) {
-  hipLaunchKernelGGL(lml_scalars_kernel<double>, dim3(1, 1, (unsigned)tl_batch.k), dim3(1024), 0, s, L,
+  GOGP_KLAUNCH(lml_scalars_kernel<double>, dim3(1, 1, (unsigned)tl_batch.k), dim3(1024), 0, s, L,
                      (long)ld, z, y, alpha, (long)n, scalars, tl_batch.stride);
 }
 void launch_lml_scalars(hipStream_t s, const float *L, int64_t ld, const double *z,
                         const double *y, const double *alpha, int64_t n, double *scalars) {
-  hipLaunchKernelGGL(lml_scalars_kernel<float>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
+  GOGP_KLAUNCH(lml_scalars_kernel<float>, dim3(1), dim3(1024), 0, s, L, (long)ld, z, y, alpha,
                      (long)n, scalars, 0L);
 }
 
@@ -322,14 +322,55 @@ __global__ __launch_bounds__(256) void rownorm_dot_kernel(const T *__restrict__ 
 void launch_rownorm_dot(hipStream_t s, const double *V, int64_t ld, const double *vec,
                         int64_t ncols, int64_t m, double *dot, double *sq) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(rownorm_dot_kernel<double>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
+  GOGP_KLAUNCH(rownorm_dot_kernel<double>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
                      (long)ncols, dot, sq);
 }
 void launch_rownorm_dot(hipStream_t s, const float *V, int64_t ld, const double *vec,
                         int64_t ncols, int64_t m, double *dot, double *sq) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(rownorm_dot_kernel<float>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
+  GOGP_KLAUNCH(rownorm_dot_kernel<float>, dim3((unsigned)m), dim3(256), 0, s, V, (long)ld, vec,
                      (long)ncols, dot, sq);
+}
+
+// fp32 path, gradient: out[0] = sum_{i < n} (alpha_i^2 - sum_{q >= q0(i)} Y[i][q]^2) = |alpha|^2 - tr(K^-1) with
+// tr(K^-1) = |Y|_F^2 summed in fp64 from Y = L^-T itself (q0: first column of row i's 256-block; what lies left of it
+// is never written) -- instead of the diagonal of the fp32 product Y Y^T, whose entries carry the fp32 accumulation
+// of up to N squares.  One workgroup per row writes part[i]; a single workgroup adds them in a fixed order.
+template <class T>
+__global__ __launch_bounds__(256) void trace_rows_kernel(const T *__restrict__ Y, long ld, long ncols,
+                                                         const double *__restrict__ alpha, double *__restrict__ part) {
+  __shared__ double red[4];
+  const long i = blockIdx.x;
+  const long q0 = (i / PANEL) * PANEL;
+  const T *row = Y + i * ld;
+  double b = 0.0;
+  for (long q = q0 + threadIdx.x; q < ncols; q += 256) {
+    const double v = (double)row[q];
+    b += v * v;
+  }
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) part[i] = alpha[i] * alpha[i] - ((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(1024) void sum_kernel(const double *__restrict__ v, long n, double *__restrict__ out) {
+  __shared__ double red[16];
+  double a = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) a += v[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
+  }
+}
+void launch_trace_from_y(hipStream_t s, const float *Y, int64_t ld, int64_t n, int64_t npad, const double *alpha,
+                         double *part, double *out) {
+  if (n <= 0) return;
+  GOGP_KLAUNCH(trace_rows_kernel<float>, dim3((unsigned)n), dim3(256), 0, s, Y, (long)ld, (long)npad, alpha, part);
+  GOGP_KLAUNCH(sum_kernel, dim3(1), dim3(1024), 0, s, (const double *)part, (long)n, out);
 }
 
 // Zero the STRICTLY upper 256-block triangle of a matrix: row r, columns
@@ -350,13 +391,13 @@ __global__ __launch_bounds__(256) void zero_upper_kernel(T *__restrict__ R, long
 void launch_zero_upper_blocks(hipStream_t s, double *R, int64_t ld, int64_t npad) {
   if (npad <= PANEL) return;
   dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL), (unsigned)tl_batch.k);
-  hipLaunchKernelGGL(zero_upper_kernel<double>, grid, dim3(256), 0, s, R, (long)ld, (long)npad,
+  GOGP_KLAUNCH(zero_upper_kernel<double>, grid, dim3(256), 0, s, R, (long)ld, (long)npad,
                      tl_batch.stride);
 }
 void launch_zero_upper_blocks(hipStream_t s, float *R, int64_t ld, int64_t npad) {
   if (npad <= PANEL) return;
   dim3 grid((unsigned)((npad / 2 + 255) / 256), (unsigned)(npad - PANEL));
-  hipLaunchKernelGGL(zero_upper_kernel<float>, grid, dim3(256), 0, s, R, (long)ld, (long)npad, 0L);
+  GOGP_KLAUNCH(zero_upper_kernel<float>, grid, dim3(256), 0, s, R, (long)ld, (long)npad, 0L);
 }
 
 // Y[c0+i][c0+j] = Dinv[j][i]  (256x256 transpose of a diagonal-block inverse into
@@ -377,11 +418,11 @@ __global__ __launch_bounds__(256) void ydiag_kernel(const T *__restrict__ Dinv,
 }
 
 void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld) {
-  hipLaunchKernelGGL(ydiag_kernel<double>, dim3(64, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv, Ydiag,
+  GOGP_KLAUNCH(ydiag_kernel<double>, dim3(64, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv, Ydiag,
                      (long)ld, tl_batch.stride);
 }
 void launch_ydiag(hipStream_t s, const float *Dinv, float *Ydiag, int64_t ld) {
-  hipLaunchKernelGGL(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld, 0L);
+  GOGP_KLAUNCH(ydiag_kernel<float>, dim3(64), dim3(256), 0, s, Dinv, Ydiag, (long)ld, 0L);
 }
 
 // ---- inverse of a super-panel's triangular diagonal block (api.hip: assemble_tinv) -------------------------------
@@ -424,11 +465,11 @@ __global__ __launch_bounds__(256) void tinv_init_kernel(const T *__restrict__ Di
   }
 }
 void launch_tinv_init(hipStream_t s, const double *Dinv, double *X, double *XT, int nsub, int64_t tld) {
-  hipLaunchKernelGGL(tinv_init_kernel<double>, dim3(nsub * 8 * nsub * 8, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv,
+  GOGP_KLAUNCH(tinv_init_kernel<double>, dim3(nsub * 8 * nsub * 8, 1, (unsigned)tl_batch.k), dim3(256), 0, s, Dinv,
                      X, XT, nsub, (long)tld, tl_batch.stride);
 }
 void launch_tinv_init(hipStream_t s, const float *Dinv, float *X, float *XT, int nsub, int64_t tld) {
-  hipLaunchKernelGGL(tinv_init_kernel<float>, dim3(nsub * 8 * nsub * 8), dim3(256), 0, s, Dinv, X, XT, nsub, (long)tld, 0L);
+  GOGP_KLAUNCH(tinv_init_kernel<float>, dim3(nsub * 8 * nsub * 8), dim3(256), 0, s, Dinv, X, XT, nsub, (long)tld, 0L);
 }
 
 // Up to BLOCKMM_MAX products C_b (256 x 256) = alpha * A_b (256 x K_b) * B_b (K_b x 256) in ONE launch, all row-major
@@ -519,7 +560,7 @@ static void launch_blockmm_t(hipStream_t s, int nprod, const T *const *A, const 
   }
   g.alpha = alpha;
   g.bstride = bstride;
-  hipLaunchKernelGGL(blockmm_kernel<T>, dim3(16, (unsigned)nprod, nz), dim3(256), 0, s, g);
+  GOGP_KLAUNCH(blockmm_kernel<T>, dim3(16, (unsigned)nprod, nz), dim3(256), 0, s, g);
 }
 void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
                     const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha) {
@@ -544,13 +585,13 @@ __global__ __launch_bounds__(256) void zero_block_kernel(T *__restrict__ B, long
 void launch_zero_block(hipStream_t s, double *B, int64_t ld, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return;
   dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows, (unsigned)tl_batch.k);
-  hipLaunchKernelGGL(zero_block_kernel<double>, grid, dim3(256), 0, s, B, (long)ld, (long)cols,
+  GOGP_KLAUNCH(zero_block_kernel<double>, grid, dim3(256), 0, s, B, (long)ld, (long)cols,
                      tl_batch.stride);
 }
 void launch_zero_block(hipStream_t s, float *B, int64_t ld, int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return;
   dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
-  hipLaunchKernelGGL(zero_block_kernel<float>, grid, dim3(256), 0, s, B, (long)ld, (long)cols, 0L);
+  GOGP_KLAUNCH(zero_block_kernel<float>, grid, dim3(256), 0, s, B, (long)ld, (long)cols, 0L);
 }
 
 __global__ void fill_kernel(double *p, long count, double v) {
@@ -565,7 +606,7 @@ __global__ void axpy_kernel(double *__restrict__ a, const double *__restrict__ b
 }
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (long)count);
+  GOGP_KLAUNCH(axpy_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (long)count);
 }
 
 // out[0] = sum_{i<n} a_i b_i  (single workgroup, fixed order)
@@ -584,14 +625,14 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double *__restrict__ a,
   }
 }
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out) {
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, a, b, (long)n, out);
+  GOGP_KLAUNCH(dot_kernel, dim3(1), dim3(1024), 0, s, a, b, (long)n, out);
 }
 
 void launch_fill(hipStream_t s, double *p, int64_t count, double v) {
   if (count <= 0) return;
   int blocks = (int)((count + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, (long)count, v);
+  GOGP_KLAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, s, p, (long)count, v);
 }
 
 template <class T>
@@ -606,12 +647,12 @@ __global__ void extract_lower_kernel(const T *__restrict__ L, long ld, long n,
 void launch_extract_lower(hipStream_t s, const double *L, int64_t ld, int64_t n, double *out) {
   if (n <= 0) return;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
-  hipLaunchKernelGGL(extract_lower_kernel<double>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+  GOGP_KLAUNCH(extract_lower_kernel<double>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
 }
 void launch_extract_lower(hipStream_t s, const float *L, int64_t ld, int64_t n, double *out) {
   if (n <= 0) return;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
-  hipLaunchKernelGGL(extract_lower_kernel<float>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
+  GOGP_KLAUNCH(extract_lower_kernel<float>, grid, dim3(256), 0, s, L, (long)ld, (long)n, out);
 }
 
 // rows x cols block conversions between the fp32 matrices and the fp64 scratch of the
@@ -624,17 +665,17 @@ __global__ __launch_bounds__(256) void convert_block_kernel(const S *__restrict_
 }
 void launch_convert_block(hipStream_t s, const float *src, int64_t lds_, double *dst, int64_t ldd,
                           int rows, int cols) {
-  hipLaunchKernelGGL((convert_block_kernel<float, double>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
+  GOGP_KLAUNCH((convert_block_kernel<float, double>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
                      dst, (long)ldd, cols);
 }
 void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, float *dst, int64_t ldd,
                           int rows, int cols) {
-  hipLaunchKernelGGL((convert_block_kernel<double, float>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
+  GOGP_KLAUNCH((convert_block_kernel<double, float>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
                      dst, (long)ldd, cols);
 }
 void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
                           int rows, int cols) {  // same type: a strided block copy
-  hipLaunchKernelGGL((convert_block_kernel<double, double>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
+  GOGP_KLAUNCH((convert_block_kernel<double, double>), dim3(rows), dim3(256), 0, s, src, (long)lds_,
                      dst, (long)ldd, cols);
 }
 
@@ -654,13 +695,13 @@ __global__ void pack_lower_kernel(const double *__restrict__ in, long n, long np
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, double *L,
                        int64_t ld) {
   dim3 grid((unsigned)((npad + 255) / 256), (unsigned)npad);
-  hipLaunchKernelGGL(pack_lower_kernel<double>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
+  GOGP_KLAUNCH(pack_lower_kernel<double>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
                      (long)ld);
 }
 void launch_pack_lower(hipStream_t s, const double *in, int64_t n, int64_t npad, float *L,
                        int64_t ld) {
   dim3 grid((unsigned)((npad + 255) / 256), (unsigned)npad);
-  hipLaunchKernelGGL(pack_lower_kernel<float>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
+  GOGP_KLAUNCH(pack_lower_kernel<float>, grid, dim3(256), 0, s, in, (long)n, (long)npad, L,
                      (long)ld);
 }
 
@@ -674,7 +715,7 @@ __global__ void sigma_kernel(const double *__restrict__ prior, const double *__r
 void launch_sigma(hipStream_t s, const double *prior, const double *q, int64_t m,
                   double *sigma) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(sigma_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, prior, q,
+  GOGP_KLAUNCH(sigma_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, prior, q,
                      (long)m, sigma);
 }
 
@@ -697,12 +738,12 @@ __global__ __launch_bounds__(256) void transpose_sq_kernel(const T *__restrict__
 void launch_transpose_sq(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd,
                          int n) {
   const int nt = n / 32;
-  hipLaunchKernelGGL(transpose_sq_kernel<double>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
+  GOGP_KLAUNCH(transpose_sq_kernel<double>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
                      (long)ldd, nt);
 }
 void launch_transpose_sq(hipStream_t s, const float *src, int64_t lds_, float *dst, int64_t ldd, int n) {
   const int nt = n / 32;
-  hipLaunchKernelGGL(transpose_sq_kernel<float>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
+  GOGP_KLAUNCH(transpose_sq_kernel<float>, dim3(nt * nt), dim3(256), 0, s, src, (long)lds_, dst,
                      (long)ldd, nt);
 }
 
@@ -729,7 +770,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(double *__restrict__ d
 void launch_pack_blocks(hipStream_t s, double *dst, const double *src, int nblk, int64_t blk,
                         int first, int stride) {
   if (nblk <= 0) return;
-  hipLaunchKernelGGL(pack_blocks_kernel, dim3(64, (unsigned)nblk), dim3(256), 0, s, dst, src,
+  GOGP_KLAUNCH(pack_blocks_kernel, dim3(64, (unsigned)nblk), dim3(256), 0, s, dst, src,
                      (long)blk, first, stride);
 }
 
@@ -772,8 +813,8 @@ template <class T>
 static void chunk_tdot_t(hipStream_t s, const T *chunk, int64_t rows, int nb, const double *v, double *part,
                          double *out) {
   const int nslab = (int)((rows + TDOT_SLAB - 1) / TDOT_SLAB);
-  hipLaunchKernelGGL(chunk_tdot_kernel<T>, dim3(nb / 64, nslab), dim3(256), 0, s, chunk, (long)rows, nb, v, part);
-  hipLaunchKernelGGL(chunk_tdot_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, part, nslab, nb, out);
+  GOGP_KLAUNCH(chunk_tdot_kernel<T>, dim3(nb / 64, nslab), dim3(256), 0, s, chunk, (long)rows, nb, v, part);
+  GOGP_KLAUNCH(chunk_tdot_finish_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, part, nslab, nb, out);
 }
 void launch_chunk_tdot(hipStream_t s, const double *chunk, int64_t rows, int nb, const double *v,
                        double *part, double *out) {
@@ -823,7 +864,7 @@ static void chunk_alpha_t(hipStream_t s, const T *Ych, int mloc, int nloc, int n
                           double *out) {
   const long rows = (long)mloc * nb;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(chunk_alpha_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc,
+  GOGP_KLAUNCH(chunk_alpha_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc,
                      nloc, nb, map, z, out);
 }
 void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map,
@@ -851,7 +892,7 @@ __global__ __launch_bounds__(256) void logdet_block_kernel(const double *__restr
 
 void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
                          double *acc) {
-  hipLaunchKernelGGL(logdet_block_kernel, dim3(1), dim3(256), 0, s, L, (long)ld, (long)row0, (long)n,
+  GOGP_KLAUNCH(logdet_block_kernel, dim3(1), dim3(256), 0, s, L, (long)ld, (long)row0, (long)n,
                      nb, acc);
 }
 
@@ -874,7 +915,7 @@ __global__ __launch_bounds__(1024) void sumsq_info_kernel(const double *__restri
 }
 
 void launch_sumsq_info(hipStream_t s, const double *z, int64_t n, const long long *info, double *out) {
-  hipLaunchKernelGGL(sumsq_info_kernel, dim3(1), dim3(1024), 0, s, z, (long)n, info, out);
+  GOGP_KLAUNCH(sumsq_info_kernel, dim3(1), dim3(1024), 0, s, z, (long)n, info, out);
 }
 
 __global__ void info_to_double_kernel(const long long *__restrict__ info, double *__restrict__ out) {
@@ -882,7 +923,7 @@ __global__ void info_to_double_kernel(const long long *__restrict__ info, double
 }
 
 void launch_info_to_double(hipStream_t s, const long long *info, double *out) {
-  hipLaunchKernelGGL(info_to_double_kernel, dim3(1), dim3(1), 0, s, info, out);
+  GOGP_KLAUNCH(info_to_double_kernel, dim3(1), dim3(1), 0, s, info, out);
 }
 
 }  // namespace gogp

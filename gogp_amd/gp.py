@@ -272,6 +272,12 @@ class GP:
         self._check(_lib.lib().gogp_set_factor(self._h, _dp(ts), _dp(tn), _dp(Lm), _dp(al)))
 
     # ---- measurement hooks ----------------------------------------------------------------
+    def graph_info(self):
+        """(nodes of the candidates' launch graph in use, whether the runtime refused an explicitly built graph)."""
+        nodes, refused = ctypes.c_int64(0), ctypes.c_int(0)
+        self._check(_lib.lib().gogp_graph_info(self._h, ctypes.byref(nodes), ctypes.byref(refused)))
+        return int(nodes.value), bool(refused.value)
+
     def set_option(self, name: str, value: int):
         self._check(_lib.lib().gogp_set_option(self._h, name.encode(), int(value)))
 

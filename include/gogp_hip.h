@@ -201,6 +201,11 @@ int gogp_observe_gradient_candidates(gogp_handle *h, int k, const double *x, int
                                      double *lmls /* k */, double *grads /* k*len */,
                                      int *status /* k */);
 
+/* Diagnostics of the candidates' launch graph (option "graph"): nodes of the graph in use (0: none yet, or the
+ * stream path), whether the runtime refused an explicitly built graph (then the stream path is used for good).
+ * No reference counterpart. */
+int gogp_graph_info(const gogp_handle *h, int64_t *nodes, int *refused);
+
 /* gp.GP.Produce (gp/gp.go:258-360): predictive mean and standard deviation of
  * the latent function at m points Z (row-major m x ndim).  sigma_j =
  * sqrt(k(z_j,z_j) - (Kstar^T K^-1 Kstar)_jj), unclamped like the reference
@@ -349,9 +354,17 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "ard_mfma_min_dims" 1..65  ARD kernels with one radial term and at least this many dimensions run
  *                          the gradient reduction with distances and per-dimension sums on the matrix
  *                          cores (grad_mfma.hip); 65: never                                 (default 1)
- *   "graph"        1 | 0   gogp_observe_gradient_candidates up to N = 1024: capture the launch
- *                          sequence into a hipGraph on its second identical use and replay it
- *                          (parameters and data may change, sizes may not)              (default 1)
+ *   "graph"        0..2    gogp_observe_gradient_candidates: on its second identical use the launch sequence
+ *                          becomes a hipGraph and is replayed (parameters and data may change, sizes may not).
+ *                          1: an explicitly built graph -- one node per launch / copy, the sweep's real
+ *                          cross-stream dependencies as edges, no stream capture -- up to N = 8192;
+ *                          2: round 2's linear graph from stream capture, N <= 1024; 0: streams (default 1)
+ *   "produce_tinv", "produce_panels", "produce_groups", "produce_small_below"
+ *                          gogp_produce: whole super-panels of `produce_panels` 256-column panels solved through
+ *                          the inverse of the factor's diagonal block (1) or panel by panel (0); the test
+ *                          points' tile rows on `produce_groups` independent chains; 64 x 64 tiles for launches
+ *                          below that many 128-tiles                                  (default 1, 4, 2, 1024)
+ *   "krag"         1 | 0   the triangular inverse's updates skip the zero triangle of a super-panel of Y (default 1)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 
