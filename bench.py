@@ -565,6 +565,19 @@ def main():
                     "major_iterations": res.iterations, "evaluations": res.evaluations, "seconds": tl,
                     "evals_per_s": res.evaluations / tl, "lml_start": res.history[0], "lml_end": res.lml,
                     "note": "optimize.lbfgs over the sharded handle, the same iterate sequence on every rank"}
+                # k = 2 candidates per call on the shards (gogp_observe_gradient_candidates: evaluated one after the
+                # other in the shards' own tiles): against two single calls, bit for bit
+                xs2 = np.stack([wl.log_theta(1), wl.log_theta(2)])
+                single = [(sg.Observe(x), sg.Gradient()) for x in xs2]
+                sync()
+                tc = time.perf_counter()
+                lm2, gr2, st2 = sg.observe_gradient_candidates(xs2)
+                sync()
+                tc = time.perf_counter() - tc
+                lbfgs_sharded["candidates_k2"] = {
+                    "seconds": tc, "evals_per_s": 2.0 / tc, "status": [int(v) for v in st2],
+                    "bit_identical_to_single_calls": bool(all(lm2[c] == single[c][0] and np.array_equal(gr2[c], single[c][1])
+                                                              for c in range(2)))}
             except Exception as e:  # noqa: BLE001
                 lbfgs_sharded = {"error": repr(e)[:200]}
 

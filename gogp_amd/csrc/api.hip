@@ -1129,11 +1129,10 @@ static void assemble_gradient(const gogp_handle *h, const double *a, double dnoi
 //                  refined alpha; v: the noise variance on the diagonal) -- one radial term with an output scale.
 // Measured on the stress case of round 3 (Matern-3/2, N = 1721, D = 2, gradient error 3.6e-3 of its largest
 // component, all of it in the scale slot): tests/test_gpu_parity.py::test_fp32_gradient_ill_conditioned_case.
-static void fp32_gradient_identities(const gogp_handle *h, double *a, double trace_w) {
+static void fp32_gradient_identities(const gogp_handle *h, double *a, double trace_w, double yta, double noise_var) {
   const gogp_desc &d = h->desc;
   a[ACC_TRACE] = trace_w;
-  if (d.nterms == 1 && d.terms[0].scale_idx >= 0)
-    a[0] = (h->yta - (double)h->n) - h->hostP->noise_var * trace_w;
+  if (d.nterms == 1 && d.terms[0].scale_idx >= 0) a[0] = (yta - (double)h->n) - noise_var * trace_w;
 }
 
 extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
@@ -1176,7 +1175,8 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
     }
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
-    if (h->prec == 32 && std::isfinite(h->hscal[9])) fp32_gradient_identities(h, h->hscal + 16, h->hscal[9]);
+    if (h->prec == 32 && std::isfinite(h->hscal[9]))
+      fp32_gradient_identities(h, h->hscal + 16, h->hscal[9], h->yta, h->hostP->noise_var);
   }
   if (!h->grad_valid) {
     h->grad_cache.assign(h->P, 0.0);
@@ -1246,7 +1246,7 @@ constexpr int64_t GRAPH_EXPLICIT_MAX_NPAD = 8192;  // option "graph" = 2: the sw
 struct CandLayout {
   size_t devP, info, scalars, gout, bufA, bufL, bufY, Dinv, z, w, alpha, gpart, total;
 };
-static CandLayout cand_layout(int64_t npad) {
+static CandLayout cand_layout(int64_t npad, size_t esz = sizeof(double)) {
   CandLayout L;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -1254,7 +1254,7 @@ static CandLayout cand_layout(int64_t npad) {
     o += align_up(bytes, 256);
     return at;
   };
-  const size_t nn = (size_t)npad * (size_t)npad * sizeof(double);
+  const size_t nn = (size_t)npad * (size_t)npad * esz;  // matrices: float on the fp32 path
   L.devP = take(sizeof(DevParams));
   L.info = take(sizeof(long long));
   L.scalars = take(8 * sizeof(double));
@@ -1263,7 +1263,7 @@ static CandLayout cand_layout(int64_t npad) {
   L.w = take((size_t)npad * sizeof(double));
   L.alpha = take((size_t)npad * sizeof(double));
   L.gpart = take((size_t)grad_reduce_blocks(npad) * NACC * sizeof(double));
-  L.Dinv = take((size_t)(npad / PANEL) * PANEL * PANEL * sizeof(double));
+  L.Dinv = take((size_t)(npad / PANEL) * PANEL * PANEL * esz);
   L.bufA = take(nn);
   L.bufL = take(nn);
   L.bufY = take(nn);
@@ -1293,7 +1293,7 @@ static int ensure_candidates(gogp_handle *h, int k) {
     h->cand_cap_k = 0;
     h->cand_cap_npad = 0;
     const int64_t cap = std::max(h->npad, h->cand_cap_npad);
-    const CandLayout L = cand_layout(cap);
+    const CandLayout L = cand_layout(cap, h->esz());
     HIPCHK(h, hipMalloc((void **)&h->cand_arena, L.total * (size_t)k));
     h->cand_stride = L.total;
     h->cand_cap_k = k;
@@ -1308,8 +1308,46 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   if (k > GOGP_MAX_CANDIDATES) return fail(h, GOGP_EARG, "candidates: k > GOGP_MAX_CANDIDATES");
   if (len != h->P) return fail(h, GOGP_EARG, "len(x)");  // gp/gp.go:398-400
   if (!h->have_data) return fail(h, GOGP_ESTATE, "candidates: no data (gogp_set_data)");
-  if (h->dist) return fail(h, GOGP_EARG, "candidates: not available on a sharded handle");
-  if (h->prec != 64) return fail(h, GOGP_EARG, "candidates: fp64 path only");
+  if (h->dist) {
+    // Sharded handle: the k candidates are evaluated one after the other in the shards' own tiles (an arena of k more
+    // shards is exactly what a sharded evaluation has no memory for, and at the sizes that are sharded one evaluation
+    // fills the GPUs by itself).  Collective: every rank calls with the same candidates.  Afterwards the handle holds
+    // the LAST candidate's factorisation (as after gogp_observe of it) -- unlike the single-GPU form, which leaves
+    // the handle's own state alone.
+    HIPCHK(h, hipSetDevice(h->device));
+    int first_d = GOGP_OK;
+    for (int c = 0; c < k; ++c) {
+      double *g = grads + (size_t)c * len;
+      for (int64_t i = 0; i < len; ++i) g[i] = 0.0;
+      lmls[c] = NAN;
+      h->with_obs = false;
+      int r = observe_theta(h, xs + (size_t)c * len, &lmls[c]);
+      if (r == GOGP_OK || r == GOGP_ECOND) {
+        const int rg = gogp_gradient(h, g, len);
+        if (rg != GOGP_OK) r = rg;
+      } else if (r == GOGP_ENOTPD) {
+        lmls[c] = NAN;
+      } else {
+        return r;  // a transport / HIP failure: nothing after it can be trusted
+      }
+      if (status) status[c] = r;
+      if (first_d == GOGP_OK && r != GOGP_OK) first_d = r;
+    }
+    return first_d;
+  }
+  if (h->prec == 32 && k > 1) {
+    // fp32 path: one candidate per launch sequence, k of them one after the other in ONE arena slot (the handle's own
+    // factorisation stays untouched, as on the fp64 path).  The float kernels carry no candidate index: at the sizes
+    // the fp32 path exists for, one evaluation fills the GPU.
+    int first32 = GOGP_OK;
+    for (int c = 0; c < k; ++c) {
+      const int r = gogp_observe_gradient_candidates(h, 1, xs + (size_t)c * len, len, lmls + c, grads + (size_t)c * len,
+                                                     status ? status + c : nullptr);
+      if (r != GOGP_OK && r != GOGP_ENOTPD && r != GOGP_ECOND && r != GOGP_EARG) return r;
+      if (first32 == GOGP_OK && r != GOGP_OK) first32 = r;
+    }
+    return first32;
+  }
   if (!h->lookahead || !h->eager)
     return fail(h, GOGP_EARG, "candidates: needs the fused sweep (options lookahead and eager on)");
   if (h->n == 0) {  // gp/gp.go:101-104, 427-430
@@ -1340,7 +1378,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
   } sv{h->devP, h->info, h->scalars, h->gout, h->bufA, h->bufL, h->bufY, h->Dinv, h->z, h->w, h->alpha,
        h->gpart, h->hscal, h->cap_y, h->notpd, h->factored, h->have_alpha, h->have_kinv, h->observed,
        h->with_obs, h->grad_valid, h->trtri_done, h->lml, h->cond_lb, h->theta_s, h->theta_n};
-  const CandLayout L = cand_layout(h->cand_cap_npad);
+  const CandLayout L = cand_layout(h->cand_cap_npad, h->esz());
   char *a0 = h->cand_arena;
   h->devP = (DevParams *)(a0 + L.devP);
   h->info = (long long *)(a0 + L.info);
@@ -1380,18 +1418,29 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     for (int c = 0; c < k; ++c)
       HIPCHK(h, gogp::rec_memcpy_async((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c,
                                        sizeof(DevParams), hipMemcpyHostToDevice, h->s));
-    int r = factorize_t<double>(h, true);
+    const bool f32 = h->prec == 32;
+    int r = f32 ? factorize_t<float>(h, true) : factorize_t<double>(h, true);
     if (r != GOGP_OK) return r;
-    r = compute_kinv_t<double>(h);
+    r = f32 ? compute_kinv_t<float>(h) : compute_kinv_t<double>(h);
     if (r != GOGP_OK) return r;
     r = ensure_alpha(h);
     if (r != GOGP_OK) return r;
     {
       AuxTimer tm(h, GOGP_PROF_GRAD, h->s);
-      launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n, h->npad,
-                         h->gpart, h->gout, h->radial1, h->ard_mfma_min);
+      if (f32)
+        launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, reinterpret_cast<const float *>(h->bufA),
+                           h->npad, h->n, h->npad, h->gpart, h->gout, h->radial1, h->ard_mfma_min);
+      else
+        launch_grad_reduce(h->s, h->devP, h->D, h->ard_dims, h->dX, h->alpha, h->bufA, h->npad, h->n, h->npad,
+                           h->gpart, h->gout, h->radial1, h->ard_mfma_min);
     }
     HIPCHK(h, cand_d2h(h, h->hscal + 16, h->gout, NACC * sizeof(double), h->s));
+    h->hscal[9] = NAN;
+    if (f32 && h->trace_fp64) {  // the fp32 path's closed-form components (fp32_gradient_identities)
+      launch_trace_from_y(h->s, reinterpret_cast<const float *>(h->bufY), h->npad, h->n, h->npad, h->alpha, h->rw,
+                          h->scalars + 7);
+      HIPCHK(h, hipMemcpyAsync(h->hscal + 9, h->scalars + 7, sizeof(double), hipMemcpyDeviceToHost, h->s));
+    }
     // every stream joins the main one (the end of a captured graph; harmless otherwise)
     size_t slot = EV_BASE + 4 * (size_t)(h->npad / PANEL);  // the four event slots behind the panels' own
     for (hipStream_t q : {h->sp, h->s2, h->st, h->sl, h->sk}) order(h, slot++, q, h->s);
@@ -1406,7 +1455,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     // the streams, but this runtime executes parallel branches no faster than their serialisation (N = 4096: 6.1 ms
     // against 3.7 ms on the streams), so it is not the default.  0: streams.
     const bool dag = h->use_graph == 2;
-    const bool graph = h->use_graph && !h->prof.on && !h->graph_failed &&
+    const bool graph = h->use_graph && h->prec == 64 && !h->prof.on && !h->graph_failed &&
                        h->npad <= (dag ? GRAPH_EXPLICIT_MAX_NPAD : GRAPH_MAX_NPAD);
     auto &key = h->cand_graph_key;
     auto same = [&](const decltype(h->cand_graph_key) &q) {
@@ -1534,10 +1583,13 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
       for (int64_t i = 0; i < len; ++i) g[i] = 0.0;
       lmls[c] = NAN;
       if (st[(size_t)c] == GOGP_OK) {
-        const FactorResult fr = judge_scalars(h, hs, false, false);
+        const bool f32 = h->prec == 32;
+        const FactorResult fr = judge_scalars(h, hs, f32, f32);
         st[(size_t)c] = fr.rc;
         if (fr.rc != GOGP_ENOTPD) {
           lmls[c] = fr.lml;
+          if (f32 && std::isfinite(hs[9]))
+            fp32_gradient_identities(h, const_cast<double *>(hs) + 16, hs[9], fr.yta, h->cand_hostP[c].noise_var);
           assemble_gradient(h, hs + 16, h->cand_hostP[c].dnoise, g);
         }
         if (fr.rc != GOGP_OK && first_msg.empty()) first_msg = fr.msg;
@@ -2028,6 +2080,7 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
       for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
       free_n_buffers(h);
       free_m_buffers(h);
+      free_cand_buffers(h);  // the candidates' arena slots are laid out for the matrices' element type
       h->prec = (int)value;
       h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
       h->trtri_done = h->trtri_pending = h->alpha_pending = h->kinv_pending = false;

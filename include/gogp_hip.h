@@ -195,7 +195,10 @@ int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double *x, int64_
  * ~3 x 8 N^2 bytes each that stay allocated until the handle is destroyed.  status[c] (may be
  * NULL): GOGP_OK, GOGP_ENOTPD (lmls[c] = NaN, gradient zeros), GOGP_ECOND (values still
  * returned) or GOGP_EARG (parameters not finite); the result is the first non-zero one.
- * fp64 handles on one GPU only; k <= GOGP_MAX_CANDIDATES. */
+ * k <= GOGP_MAX_CANDIDATES.  fp64 handle on one GPU: as described.  precision = 32: the candidates pass through
+ * ONE arena slot one after the other (same results and the same untouched handle; the float kernels carry no
+ * candidate index).  Sharded handle (collective: every rank with the same candidates): evaluated one after the
+ * other in the shards' own tiles, and the handle afterwards holds the LAST candidate's factorisation. */
 #define GOGP_MAX_CANDIDATES 16
 int gogp_observe_gradient_candidates(gogp_handle *h, int k, const double *x, int64_t len,
                                      double *lmls /* k */, double *grads /* k*len */,

@@ -1001,6 +1001,40 @@ def test_candidates_explicit_graph_with_the_sweeps_dependencies_is_bit_identical
     g.close()
 
 
+def test_candidates_on_the_fp32_path(gpmod):
+    """precision = 32: the candidates go through ONE arena slot one after the other (the float kernels carry no
+    candidate index); every bit equals the single fp32 Observe + Gradient calls, the handle's own factorisation is
+    left alone, and the line search with k trial points per call follows the k = 1 path."""
+    from gogp_amd import optimize
+    rng = np.random.default_rng(99)
+    n, D = 2100, 4
+    X, y = _data(rng, n, D)
+    simil, noise = kernel.Scaled(kernel.ARD(kernel.Normal, D)), kernel.UniformNoise
+    base = np.log(np.concatenate([[1.0], np.full(D, 0.8), [0.2]]))
+    xs = np.stack([base + 0.04 * c for c in range(4)])
+    g = gpmod.GP(D, simil, noise, X=X, Y=y, precision=32)
+    want = [(g.Observe(x), g.Gradient()) for x in xs]
+    lml_own, grad_own = g.Observe(base - 0.1), g.Gradient()
+    Z = rng.uniform(0, 1, (9, D))
+    mu_own, sigma_own = g.Produce(Z)
+    for rep in range(2):
+        lmls, grads, st = g.observe_gradient_candidates(xs)
+        assert list(st) == [0] * 4
+        for c in range(4):
+            assert lmls[c] == want[c][0]
+            np.testing.assert_array_equal(grads[c], want[c][1])
+    assert g.LML() == lml_own
+    np.testing.assert_array_equal(g.Gradient(), grad_own)
+    mu2, sigma2 = g.Produce(Z)
+    np.testing.assert_array_equal(mu2, mu_own)
+    np.testing.assert_array_equal(sigma2, sigma_own)
+    r1 = optimize.lbfgs(g, base, major_iterations=3, gradient_threshold=1e-12)
+    r3 = optimize.lbfgs(g, base, major_iterations=3, gradient_threshold=1e-12, line_search_candidates=3)
+    np.testing.assert_array_equal(r1.x, r3.x)
+    assert r1.history == r3.history
+    g.close()
+
+
 def test_candidates_graph_survives_arena_reallocation(gpmod):
     """The captured launch sequence holds raw pointers into the candidates' arena at ONE slot stride.
     (k=4, n=1000) sizes the arena for npad 1024; with n=500 on the same handle (k=4, n=500) twice

@@ -159,6 +159,50 @@ def test_lbfgs_over_sharded_handle(grid, precision):
     np.testing.assert_allclose(got.history[:3], want.history[:3], rtol=max(tol, 1e-9))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("grid", [(1, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
+def test_candidates_on_a_sharded_handle(grid, precision):
+    """gogp_observe_gradient_candidates on the shards (tutorial/tutorial.go:30,141: candidates of the optimiser): the k
+    candidates are evaluated one after the other in the shards' own tiles -- every bit of LML and gradient equals k
+    single Observe + Gradient calls on the same sharded handle, identical on all ranks; a candidate that is not
+    positive definite only marks its own status; optimize.lbfgs(line_search_candidates = k) runs over it and takes
+    the identical path as k = 1."""
+    from gogp_amd import kernel, optimize, synth
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    world = grid[0] * grid[1]
+    n, D = 1500, 3
+    simil = kernel.Scaled(kernel.ARD(kernel.Normal, D))
+    X, y = synth.make_inputs(n, D, 78)
+    base = np.log(np.concatenate([[0.8], np.full(D, 0.9), [0.3]]))
+    xs = np.stack([base + 0.05 * c for c in range(3)])
+    x0 = base.copy()
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                       exchange=lb.exchange, allreduce=lb.allreduce, precision=precision)
+        single = [(sh.Observe(x), sh.Gradient()) for x in xs]
+        lmls, grads, st = sh.observe_gradient_candidates(xs)
+        res1 = optimize.lbfgs(sh, x0, major_iterations=3, gradient_threshold=1e-12)
+        res3 = optimize.lbfgs(sh, x0, major_iterations=3, gradient_threshold=1e-12, line_search_candidates=3)
+        sh.close()
+        return single, lmls, grads, list(st), res1, res3
+
+    outs, _ = loopback.run_ranks(world, rank_fn)
+    # (the rehearsal's host all-reduce adds the ranks' contributions in arrival order: two evaluations of the same
+    # point agree to the last bits, not bit for bit, on eight rank threads -- hence 1e-12, not array_equal)
+    for single, lmls, grads, st, res1, res3 in outs:
+        assert st == [0, 0, 0]
+        for c in range(3):
+            assert abs(lmls[c] - single[c][0]) <= 1e-12 * abs(single[c][0])
+            np.testing.assert_allclose(grads[c], single[c][1], rtol=1e-12, atol=1e-12 * np.abs(single[c][1]).max())
+        np.testing.assert_array_equal(lmls, outs[0][1])  # the same on every rank: the all-reduced values
+        np.testing.assert_array_equal(grads, outs[0][2])
+        np.testing.assert_allclose(res3.x, res1.x, rtol=0, atol=1e-8)      # the same optimisation path
+        np.testing.assert_allclose(res3.history, res1.history, rtol=1e-10)
+
+
 def expected_exchange_bytes(npad, grid, nb=512):
     """Bytes sent over the transport by ONE sharded evaluation (all ranks together), from the
     layout alone -- DESIGN.md section 5: per block column P the inverse of the diagonal tile goes

@@ -26,9 +26,10 @@ while time.time() < t_end:
     for ov in sys.argv[3:]:                          # NAME=VALUE options for every handle (A/B of a default)
         g.set_option(ov.split("=")[0], int(ov.split("=")[1]))
     tol = {"lml": 1e-8, "grad": 1e-6, "mu": 1e-6, "sigma": 1e-5} if prec == 64 else \
-          {"lml": 3e-4, "grad": 1e-2, "mu": 3e-2, "sigma": 3e-3}  # fp32: errors follow the conditioning (seed 7:
-                                                                   # matern32, n = 1721, D = 2: gradient 3.6e-3 with
-                                                                   # round 2's and round 3's tile kernel alike)
+          {"lml": 3e-4, "grad": 3e-3, "mu": 3e-2, "sigma": 3e-3}  # fp32: errors follow the conditioning.  Round 3
+                                                                   # widened grad to 1e-2 for seed 7 (matern32, n = 1721,
+                                                                   # D = 2: 3.6e-3, all in the scale component); round 4
+                                                                   # takes that component from its closed form: back to 3e-3
     o = FastOracle(D, simil, noise)
     for rep in range(int(rng.integers(1, 5))):       # the same handle with changing data sizes
         n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
