@@ -753,6 +753,29 @@ def main():
                         "one-launch-sequence form"}
             for gg in gps[1:]:
                 gg.close()
+        if world == 1 and prec == 64 and cps == 1 and N >= 4096 and g is not None and not args.no_produce:
+            # beyond the native-fp64 roof with LML / mu / sigma untouched -- "compute only the
+            # gradient's K^-1 in fp32 MFMA".  Option gradient_precision = 32: fp64 factorisation, LML, alpha, Produce;
+            # Y = L^-T and K^-1 = Y Y^T on the fp32 tile kernel.  Reported beside `value`, never as it.
+            lml_n = g.Observe(wl.log_theta(0)); grad_n = g.Gradient()
+            g.set_option("gradient_precision", 32)
+            lml_m = g.Observe(wl.log_theta(0)); grad_m = g.Gradient()
+            torch.cuda.synchronize()
+            reps = max(3, steps // 2)
+            tm = time.perf_counter()
+            for r in range(reps):
+                g.Observe(wl.log_theta(1 + r)); g.Gradient()
+            torch.cuda.synchronize()
+            tm = (time.perf_counter() - tm) / reps
+            g.set_option("gradient_precision", 64)
+            out["mixed_precision_gradient"] = {
+                "evals_per_s": 1.0 / tm, "ms_per_eval": tm * 1e3,
+                "lml_identical_to_native": bool(lml_m == lml_n),
+                "grad_rel_diff_vs_native": float(np.abs(grad_m - grad_n).max() / max(1e-300, np.abs(grad_n).max())),
+                "note": "option gradient_precision = 32 (not the default, not `value`): fp64 Cholesky / LML / alpha / "
+                        "Produce, the triangular inverse and K^-1 = Y Y^T in fp32 from a float copy of the fp64 factor, "
+                        "trace and output-scale components of the gradient from closed forms; the reference checks "
+                        "its gradient to 1e-4 (gp_test.go:170,248)"}
         if world == 1 and not args.no_produce and g is not None:
             # configs[4] words the workload as "LML+grad inside L-BFGS hyperparameter loop": a few major
             # iterations of the optimiser on this handle (gogp_amd/optimize.py) -- the same

@@ -16,6 +16,7 @@
 namespace gogp {
 
 constexpr int GR_BLOCKS_MAX = 2048;
+constexpr int GR_MAX_ARD_SLOTS = 32;  // the widest instance the launchers use: zero rows behind CjT in LDS
 
 // LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
 // grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
   partials = cand(partials, bstride);
   const int D = P.ndim;
   double *Ri = sm;              // [64][D]
-  double *CjT = sm + 64 * D;    // [D][64]
-  double *ai = sm + 128 * D;    // [64]
+  double *CjT = sm + 64 * D;    // [D + ARD_D][64]: ARD_D zero rows behind the D real ones (see the ARD pass below)
+  double *ai = CjT + 64 * (D + (ARD_D > 0 ? ARD_D : 0));  // [64]
   double *aj = ai + 64;         // [64]
   double *red = aj + 64;        // [4][NACC]
   const int tid = threadIdx.x;
@@ -48,6 +49,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
 #pragma unroll
   for (int q = 0; q < (ARD_D > 0 ? ARD_D : 1); ++q) ard[q] = 0.0;
 
+  // zero rows D .. D + ARD_D - 1 of CjT, written once: a pass's slots beyond the last dimension read them (and X a
+  // few doubles past its row: the X buffer carries zeroed slack) and multiply by inv_len = 0 -- exact zeros, never
+  // 0 * (whatever LDS held)
+  for (int idx = threadIdx.x; idx < 64 * (ARD_D > 0 ? ARD_D : 0); idx += 256) CjT[64 * D + idx] = 0.0;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     int ti, tj;
     long r0, c0, lr0, lc0;
@@ -71,7 +76,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
     for (int idx = tid; idx < 64 * D; idx += 256) {
       const int r = idx / D, d = idx - r * D;
       Ri[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
-      CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+    }
+    // lanes along a row of CjT: conflict-free stores (with the lanes along d a wave's stores were 512 B apart, one
+    // bank: 34 % of this kernel's LDS cycles were conflict cycles in the round-3 PMC pass)
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+      const int d = idx >> 6, r = idx & 63;
+      CjT[idx] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
     }
     if (tid < 64) ai[tid] = (r0 + tid < n) ? alpha[r0 + tid] : 0.0;
     else if (tid < 128) aj[tid - 64] = (c0 + tid - 64 < n) ? alpha[c0 + tid - 64] : 0.0;
@@ -129,9 +139,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(
         // LDS offsets, 32 `d < D` masks and 32 parameter addresses out of the tile loop and parked them
         // in spill lanes: 190 SGPR spills in this instance.)
         // No test of `ard0 + q < D` either (32 more hoisted masks): a slot beyond the last dimension
-        // multiplies by inv_len = 0 (fill_params zero-fills the table up to GOGP_MAX_NDIM), reads LDS past
-        // the column block (in range or, past the allocation, zero) and X past the row (the X buffer is
-        // allocated with GOGP_MAX_NDIM doubles of slack), and the host never looks at it.  The launcher
+        // multiplies by inv_len = 0 (fill_params zero-fills the table up to GOGP_MAX_NDIM), reads the zero
+        // rows behind the column block in LDS and X past the row (the X buffer is allocated with
+        // GOGP_MAX_NDIM zeroed doubles of slack): it adds exact zeros.  The launcher
         // picks the instance of each pass by the dimensions that are left, so at most half of a pass is
         // such padding.
         const double *cja = cj + ard0 * 64;
@@ -232,7 +242,7 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const unsigned nz = (unsigned)tl_batch.k;
-  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+  const size_t lds = (size_t)(128 * ndim + 64 * GR_MAX_ARD_SLOTS + 128 + 4 * NACC) * sizeof(double);
 // More than 16 ARD dimensions: passes of 16 per-dimension accumulators each.  (Instances with 32 / 64
 // accumulators need more than 256 VGPRs; the code hipcc (ROCm 7.2) generates for them -- VGPRs that carry
 // SGPR spill lanes copied through AGPRs -- returned wrong, run-to-run varying sums on the sharded
@@ -298,7 +308,7 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
   const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
-  const size_t lds = (size_t)(128 * ndim + 128 + 4 * NACC) * sizeof(double);
+  const size_t lds = (size_t)(128 * ndim + 64 * GR_MAX_ARD_SLOTS + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
   do {                                                                                            \
     if (radial1)                                                                                  \

@@ -58,7 +58,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const DevParams *__restrict__
   for (int idx = tid; idx < 64 * D; idx += 256) {
     const int r = idx / D, d = idx - r * D;
     Ri[idx] = (r0 + r < nrows) ? Rsrc[(r0 + r) * D + d] : 0.0;
-    CjT[d * 64 + r] = (c0 + r < ncols) ? Csrc[(c0 + r) * D + d] : 0.0;
+  }
+  // the transposed copy with the LANES along a row of CjT (consecutive LDS addresses): with the lanes along d the
+  // stores of a wave hit addresses 512 B apart -- one bank, D-way conflicts: SQ_LDS_BANK_CONFLICT was 64 % of this
+  // kernel's LDS cycles (round-3 PMC pass).  The strided global reads cost nothing: the tile's 64 x D inputs are one
+  // or two L2-resident lines per lane group.
+  for (int idx = tid; idx < 64 * D; idx += 256) {
+    const int d = idx >> 6, r = idx & 63;
+    CjT[idx] = (c0 + r < ncols) ? Csrc[(c0 + r) * D + d] : 0.0;
   }
   __syncthreads();
   const int tx = tid & 63, ty = tid >> 6;
@@ -145,7 +152,10 @@ __global__ __launch_bounds__(256) void gram_local_kernel(const DevParams *__rest
   for (int idx = tid; idx < 64 * D; idx += 256) {
     const int r = idx / D, d = idx - r * D;
     Ri[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
-    CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+  }
+  for (int idx = tid; idx < 64 * D; idx += 256) {  // lanes along a row of CjT: conflict-free stores (gram_kernel)
+    const int d = idx >> 6, r = idx & 63;
+    CjT[idx] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
   }
   __syncthreads();
   const long gj = c0 + tx;
@@ -224,9 +234,9 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restric
   const int tx = tid & 63, ty = tid >> 6;
   const long r0 = (long)blockIdx.x * 64;
   const int slab = blockIdx.y;
-  for (int idx = tid; idx < 64 * D; idx += 256) {
-    const int r = idx / D, d = idx - r * D;
-    RiT[d * 64 + r] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
+  for (int idx = tid; idx < 64 * D; idx += 256) {  // lanes along a row of RiT: conflict-free stores (gram_kernel)
+    const int d = idx >> 6, r = idx & 63;
+    RiT[idx] = (r0 + r < n) ? X[(r0 + r) * D + d] : 0.0;
   }
   // thread (tx, ty): row r0 + tx, columns ty*16 .. ty*16+15 of every tile
   double acc = 0.0;
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const DevParams *__restric
     __syncthreads();
     if (!RADIAL1)
       for (int idx = tid; idx < 64 * D; idx += 256) {
-        const int r = idx / D, d = idx - r * D;
-        CjT[d * 64 + r] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
+        const int d = idx >> 6, r = idx & 63;
+        CjT[idx] = (c0 + r < n) ? X[(c0 + r) * D + d] : 0.0;
       }
     if (tid < 64) vj[tid] = (c0 + tid < n) ? v[c0 + tid] : 0.0;
     __syncthreads();

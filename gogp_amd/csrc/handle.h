@@ -95,6 +95,12 @@ struct gogp_handle {
   double *TX = nullptr, *Tmt = nullptr;  // Tmt: 256 x 256 scratch blocks of the assembly
   int64_t tinv_ld = 0;
   size_t cap_tinv = 0;                   // elements allocated for TX
+  // option "gradient_precision" = 32 on an fp64 handle: the factorisation, LML, alpha and Produce stay fp64; only what
+  // the GRADIENT needs beyond them -- Y = L^-T and K^-1 = Y Y^T, 2/3 of an evaluation's flops -- runs on the fp32 tile
+  // kernel (157 TFLOP/s) from a float copy of L, in float buffers of their own (api.hip: "mixed gradient")
+  int grad_prec = 64;
+  float *g32A = nullptr, *g32L = nullptr, *g32Y = nullptr, *g32D = nullptr;  // R / K^-1, copy of L, Y, copy of Dinv
+  int64_t g32_cap = 0;
   int produce_panels = 4;                // 256-panels per super-panel of Produce's substitution
   int produce_small_below = 1024;        // Produce runs alone on the GPU: 64 x 64 tiles below this many 128-tiles (common.h: GemmGrid)
   int produce_tinv = 1;                  // option: 0 = Produce substitutes panel by panel (round 3)

@@ -367,6 +367,11 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          the inverse of the factor's diagonal block (1) or panel by panel (0); the test
  *                          points' tile rows on `produce_groups` independent chains; 64 x 64 tiles for launches
  *                          below that many 128-tiles                                  (default 1, 4, 2, 1024)
+ *   "gradient_precision" 64 | 32   on an fp64 handle: 32 runs what only the gradient needs -- Y = L^-T and
+ *                          K^-1 = Y Y^T, 2/3 of an evaluation's flops -- on the fp32 tile kernel from a float copy of
+ *                          the fp64 factor; factorisation, LML, alpha and Produce stay fp64 bit for bit (default 64)
+ *   "trace_fp64"   1 | 0   float K^-1 (precision = 32, gradient_precision = 32): tr(alpha alpha^T - K^-1) summed in
+ *                          fp64 from Y and the output-scale component from its closed form          (default 1)
  *   "krag"         1 | 0   the triangular inverse's updates skip the zero triangle of a super-panel of Y (default 1)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);

@@ -893,6 +893,46 @@ def test_fp32_gradient_ill_conditioned_case(gpmod, golden_dir):
         g.close()
 
 
+@pytest.mark.parametrize("n,D,eager", [(1500, 3, 1), (4096, 4, 1), (2300, 2, 0)])
+def test_mixed_precision_gradient_option(gpmod, n, D, eager):
+    """Option gradient_precision = 32 on an fp64 handle: the factorisation and the LML are the fp64 path's bit for bit,
+    alpha and Produce fp64 as well; only Y = L^-T and K^-1 = Y Y^T -- what the gradient alone needs, 2/3 of the flops -- run on the fp32
+    tile kernel from a float copy of the fp64 factor, and the trace / scale components come from their closed forms
+    (api.hip: mixed gradient, fp32_gradient_identities).  The reference checks its own gradient to 1e-4
+    (gp_test.go:170,248); here it stays within 1e-6 of the oracle's.  Never the default, never bench.py's `value`."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(n + D)
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(0, 1, (40, D))
+    simil, noise = kernel.Scaled(kernel.Normal), kernel.UniformNoise
+    x = np.log([1.0, math.sqrt(D / 6.0), 0.1])
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    g.set_option("eager", eager)
+    lml64, grad64, alpha64 = g.Observe(x), g.Gradient(), g.Alpha
+    mu64, sigma64 = g.Produce(Z)
+    g.set_option("gradient_precision", 32)
+    lml, grad = g.Observe(x), g.Gradient()
+    assert lml == lml64
+    # alpha: by backward substitution with the fp64 factor (the native fused sweep takes alpha = Y z from the fp64 Y
+    # it no longer has) -- the same vector to rounding, and with it Produce
+    np.testing.assert_allclose(g.Alpha, alpha64, rtol=1e-10, atol=1e-12 * np.abs(alpha64).max())
+    mu, sigma = g.Produce(Z)
+    np.testing.assert_allclose(mu, mu64, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(sigma, sigma64, rtol=1e-9, atol=1e-11)
+    o = FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    o.Observe(x)
+    grad_o = o.Gradient()
+    scale = np.abs(grad_o).max()
+    assert np.abs(grad - grad_o).max() <= 1e-6 * scale, (grad, grad_o)
+    assert np.abs(grad64 - grad_o).max() <= 1e-8 * scale
+    np.testing.assert_array_equal(g.Gradient(), grad)  # cached, repeatable
+    g.set_option("gradient_precision", 64)             # and back: the fp64 inverse again
+    assert g.Observe(x) == lml64
+    np.testing.assert_array_equal(g.Gradient(), grad64)
+    g.close()
+
+
 def test_observe_gradient_batch_matches_single_calls(gpmod):
     """k candidates evaluated at once (one host thread per handle) give bit for bit what the
     same handles return one at a time."""

@@ -110,7 +110,7 @@ extern "C" int gogp_test_grad64(int device, int64_t n, int D, int reps, const un
   if (e == hipSuccess) e = hipMemcpy(dp, &hp, sizeof hp, hipMemcpyHostToDevice);
   int rc = (e == hipSuccess) ? GOGP_OK : GOGP_ENOMEM;
   BlockMap map;  // 1 x 1 grid: local == global
-  const size_t lds = (size_t)(128 * D + 128 + 4 * NACC) * sizeof(double);
+  const size_t lds = (size_t)(128 * D + 64 * 64 + 128 + 4 * NACC) * sizeof(double);  // D + ARD_D (= 64) rows of CjT
   std::vector<double> hpart((size_t)blocks * NACC);
   int run = 0;
   auto collect = [&]() {  // fixed-order host sum of the partials of the 64-accumulator launch
