@@ -206,15 +206,20 @@ def cpu_baseline(wl, sample_n, gpu_fn, second_sample_n=0):
 
 def pmc_traffic(config, build_id):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary of the same command
-    (profiles/r03_pmc_traffic.json, written by tools/pmc_traffic.py from separate rocprofv3 --pmc passes,
+    (profiles/r04_pmc_traffic.json, written by tools/pmc_traffic.py from separate rocprofv3 --pmc passes,
     FETCH_SIZE doubled per the gfx950 correction).  The file is stamped with the build id of the library
     it was measured on (gogp_version(): hash of the library's sources); with another build the number is
     stale and is NOT reported.  Returns (entry or None, reason)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-            d = json.load(f)
-    except Exception:
-        return None, "no profiles/r03_pmc_traffic.json"
+    d = None
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest round's file that exists
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            break
+        except Exception:
+            continue
+    if d is None:
+        return None, "no profiles/r0*_pmc_traffic.json"
     e = d.get(str(config))
     if e is None:
         return None, "no PMC pass for this configuration"

@@ -1241,6 +1241,10 @@ extern "C" int gogp_gradient(gogp_handle *h, double *grad, int64_t len) {
     // sharded: every rank reduces its own tiles of K^-1, one all-reduce of the slot sums
     int rc = gogp_dist_gradient_sums(h, h->hscal + 16);
     if (rc != GOGP_OK) return rc;
+    // float tiles: the output-scale component from its closed form (fp32_gradient_identities); the trace slot already
+    // holds |alpha|^2 - |Y|_F^2 from fp64 sums over the shards' chunks of Y (dist2d.hip: gogp_dist_gradient_sums)
+    if (h->prec == 32 && h->trace_fp64)
+      fp32_gradient_identities(h, h->hscal + 16, h->hscal[16 + ACC_TRACE], h->yta, h->hostP->noise_var);
   } else if (!h->grad_valid) {
     int rc = compute_kinv(h);
     if (rc != GOGP_OK) return rc;

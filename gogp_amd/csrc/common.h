@@ -290,6 +290,11 @@ void launch_chunk_alpha(hipStream_t s, const double *Ych, int mloc, int nloc, in
                         const double *z, double *out);
 void launch_chunk_alpha(hipStream_t s, const float *Ych, int mloc, int nloc, int nb, BlockMap map,
                         const double *z, double *out);
+// out[0] = |Y_local|_F^2 over this rank's chunks of Y (rows < n), fp64; part: mloc * nb doubles
+void launch_chunk_sumsq(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map, int64_t n, double *part,
+                        double *out);
+void launch_chunk_sumsq(hipStream_t s, const float *Ych, int mloc, int nloc, int nb, BlockMap map, int64_t n, double *part,
+                        double *out);
 void launch_logdet_block(hipStream_t s, const double *L, int64_t ld, int64_t row0, int64_t n, int nb,
                          double *acc);
 void launch_sumsq_info(hipStream_t s, const double *z, int64_t n, const long long *info, double *out);

@@ -786,6 +786,7 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
     return GOGP_ENOTPD;
   }
   h->lml = -0.5 * (double)h->n * log(2 * M_PI) - 0.5 * logdet - 0.5 * zz;  // gp/gp.go:244-253
+  h->yta = zz;  // y^T alpha (float tiles: of the refined alpha) -- the output-scale identity of the fp32 gradient
   h->factored = true;
   h->have_alpha = true;
   h->have_kinv = want_kinv;
@@ -809,12 +810,22 @@ int gogp_dist_gradient_sums(gogp_handle *h, double *hacc) {
   else
     launch_grad_reduce_local(s2, h->devP, h->D, h->ard_dims, h->dX, h->alpha, d->A, d->ldA(), h->n,
                              (int64_t)d->mloc * d->nb, (int64_t)d->nloc * d->nb, d->map(), d->gpart, h->gout, h->radial1, h->ard_mfma_min);
+  // float tiles: tr(K^-1) = |Y|_F^2 and |alpha|^2 in fp64 ride along in two free slots (13, 14) of the all-reduce
+  const bool tr64 = h->prec == 32 && h->trace_fp64 && d->rloc;
+  if (tr64) {
+    launch_chunk_sumsq(s2, d->mat<float>(d->Ych), d->mloc, d->nloc, d->nb, d->map(), h->n, d->rloc, h->gout + 13);
+    launch_dot(s2, h->alpha, h->alpha, h->n, h->gout + 14);  // replicated: the all-reduce multiplies it by the ranks
+  }
   rec(h, EV_ALPHA, s2);
   wait(h, sc, EV_ALPHA);
   TRCHK(d->tr->allreduce(sc, h->gout, NACC, &e_));
   HIPCHK(h, hipMemcpyAsync(hacc, h->gout, NACC * sizeof(double), hipMemcpyDeviceToHost, sc));
   HIPCHK(h, hipStreamSynchronize(sc));
   HIPCHK(h, hipGetLastError());
+  if (tr64) {  // tr(alpha alpha^T - K^-1) from the fp64 sums over the chunks of Y instead of the float diagonal of K^-1
+    hacc[ACC_TRACE] = hacc[14] / (double)d->nranks - hacc[13];
+    hacc[13] = hacc[14] = 0.0;
+  }
   return GOGP_OK;
 }
 

@@ -876,6 +876,55 @@ void launch_chunk_alpha(hipStream_t s, const float *Ych, int mloc, int nloc, int
   chunk_alpha_t(s, Ych, mloc, nloc, nb, map, z, out);
 }
 
+// |Y_local|_F^2 of one rank over its chunks of Y = L^-T (rows < n), in fp64: part[local row] = sum over the local chunks
+// bj with gP >= gI of sum_c Ych[bj][bi][r][c]^2 (the loop of chunk_alpha_kernel), then one workgroup adds the rows in a
+// fixed order.  Summed over the ranks it is tr(K^-1) -- the float shards' gradient takes tr(alpha alpha^T - K^-1) from
+// it instead of from the float diagonal of K^-1 (api.hip: fp32_gradient_identities).
+template <class T>
+__global__ __launch_bounds__(256) void chunk_rowsq_kernel(const T *__restrict__ Ych, int mloc, int nloc, int nb,
+                                                          BlockMap map, long n, double *__restrict__ part) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long lrow = (long)blockIdx.x * 4 + wid;
+  if (lrow >= (long)mloc * nb) return;
+  const int bi = (int)(lrow / nb);
+  const int gI = bi * map.Pr + map.pr;
+  const long chunk_sz = (long)mloc * nb * nb;
+  double s0 = 0.0, s1 = 0.0;
+  if (map.grow(lrow) < n)
+    for (int bj = 0; bj < nloc; ++bj) {
+      const int gP = bj * map.Pc + map.pc;
+      if (gP < gI) continue;
+      const T *row = Ych + bj * chunk_sz + lrow * nb;
+      for (int c = lane * 2; c < nb; c += 128) {
+        double ya, yb;
+        load2(row + c, ya, yb);
+        s0 += ya * ya;
+        s1 += yb * yb;
+      }
+    }
+  double sum = s0 + s1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) part[lrow] = sum;
+}
+template <class T>
+static void chunk_sumsq_t(hipStream_t s, const T *Ych, int mloc, int nloc, int nb, BlockMap map, int64_t n, double *part,
+                          double *out) {
+  const long rows = (long)mloc * nb;
+  if (rows <= 0) return;
+  GOGP_KLAUNCH(chunk_rowsq_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Ych, mloc, nloc, nb, map, (long)n,
+               part);
+  GOGP_KLAUNCH(sum_kernel, dim3(1), dim3(1024), 0, s, (const double *)part, rows, out);
+}
+void launch_chunk_sumsq(hipStream_t s, const double *Ych, int mloc, int nloc, int nb, BlockMap map, int64_t n, double *part,
+                        double *out) {
+  chunk_sumsq_t(s, Ych, mloc, nloc, nb, map, n, part, out);
+}
+void launch_chunk_sumsq(hipStream_t s, const float *Ych, int mloc, int nloc, int nb, BlockMap map, int64_t n, double *part,
+                        double *out) {
+  chunk_sumsq_t(s, Ych, mloc, nloc, nb, map, n, part, out);
+}
+
 // acc[0] += sum_{i < nb, row0 + i < n} 2 log L[i][i]   (one diagonal block; single workgroup)
 __global__ __launch_bounds__(256) void logdet_block_kernel(const double *__restrict__ L, long ld,
                                                            long row0, long n, int nb,
