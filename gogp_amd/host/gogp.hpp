@@ -157,6 +157,10 @@ class GP {
     return L;
   }
 
+  // gogp_set_option (no reference counterpart), e.g. ("gradient_precision", 32): Observe's LML, Alpha and Produce stay
+  // fp64, what only Gradient needs runs on the fp32 matrix cores
+  void SetOption(const char *name, int64_t value) { check(gogp_set_option(h_, name, value)); }
+
   gogp_handle *handle() { return h_; }
 
  private:

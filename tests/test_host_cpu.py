@@ -153,13 +153,21 @@ def test_rank_plumbing_gloo_world2(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+def _newest_profile(suffix):
+    """The newest round's tracked profile file profiles/rNN_<suffix>."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    assert hits, suffix
+    return hits[-1]
+
+
 def test_bench_reports_pmc_traffic_only_for_the_build_it_was_measured_on():
-    """profiles/r03_pmc_traffic.json carries the build id of the library it was measured on (gogp_version():
+    """profiles/rNN_pmc_traffic.json (the newest round's) carries the build id of the library it was measured on (gogp_version():
     a hash of the library's sources); bench.py copies the number into roofline.traffic for that build only and
     says why not otherwise -- a stale file must not look like a measurement of the current kernel."""
     import json
     import bench
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+    d = json.load(open(_newest_profile("pmc_traffic.json")))
     assert d["build"] and d["3"]["N"] == 16384 and d["3"]["bytes_per_launch"] > 1e8
     e, why = bench.pmc_traffic(3, d["build"])
     assert why is None and e["bytes_per_launch"] == d["3"]["bytes_per_launch"]
@@ -175,30 +183,29 @@ def test_bench_reports_pmc_traffic_only_for_the_build_it_was_measured_on():
 
 
 def test_roofline_is_recomputable_from_the_tracked_trace():
-    """profiles/r03_c3_roofline.json must follow from profiles/r03_c3_kernel_trace.csv (the raw start / end
+    """profiles/rNN_c3_roofline.json must follow from profiles/rNN_c3_kernel_trace.csv (the raw start / end
     timestamps of every dispatch) by tools/roofline_from_profiles.py, and the bench line of the same
     profiling call from both within box-to-box spread: the numbers the judge reads are recomputable."""
     import json
     import subprocess
     import sys
     prof = os.path.join(ROOT, "profiles")
-    trace = os.path.join(prof, "r03_c3_kernel_trace.csv")
-    if not os.path.exists(trace):
-        pytest.skip("no tracked kernel trace")
+    trace = _newest_profile("c3_kernel_trace.csv")
+    rnd = os.path.basename(trace)[:3]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_from_profiles.py"), "16384",
                         "dgemm_nt_kernel", "78.6", trace], capture_output=True, text=True, check=True)
     again = json.loads(r.stdout)
-    kept = json.load(open(os.path.join(prof, "r03_c3_roofline.json")))
+    kept = json.load(open(os.path.join(prof, rnd + "_c3_roofline.json")))
     for k in ("union_ms_per_evaluation", "sum_ms_per_evaluation", "launches_per_evaluation", "frac_union"):
         assert abs(again[k] - kept[k]) <= 1e-9 * abs(kept[k]), (k, again[k], kept[k])
     assert again["evaluations_in_trace"] == kept["evaluations_in_trace"] == 6
     # frac = N^3 / union of the launch intervals / peak, nothing else
     assert abs(kept["frac_union"] - 16384.0 ** 3 / (kept["union_ms_per_evaluation"] * 1e-3) / 78.6e12) < 1e-12
     # the bench line's live HIP-event measurement of the same quantity, on another box
-    line = json.load(open(os.path.join(prof, "r03_bench_c3.json")))
+    line = json.load(open(os.path.join(prof, rnd + "_bench_c3.json")))
     assert abs(line["roofline"]["frac"] - kept["frac_union"]) < 0.03
     assert line["roofline"]["frac_wall"] <= line["roofline"]["frac"]
     # the traffic number the line carries is the stamped one, for the line's own build
-    traffic = json.load(open(os.path.join(prof, "r03_pmc_traffic.json")))
+    traffic = json.load(open(os.path.join(prof, rnd + "_pmc_traffic.json")))
     assert line["library"].endswith("build " + traffic["build"])
     assert abs(line["roofline"]["traffic"] - traffic["3"]["bytes_per_launch"]) < 1.0
