@@ -16,6 +16,7 @@ OPTS = [{}, {"lookahead": 0}, {"eager": 0}, {"superpanel": 1}, {"superpanel": 3}
 nrun = 0
 worst = {"lml": 0.0, "grad": 0.0, "mu": 0.0, "sigma": 0.0}
 worst32 = dict(worst)
+worst_mixed = 0.0
 while time.time() < t_end:
     name, D, simil, noise, ts, tn = CASES[rng.integers(0, len(CASES) - 1)]  # skip default_noise (cond 1e10)
     opts = OPTS[rng.integers(0, len(OPTS))]
@@ -25,11 +26,18 @@ while time.time() < t_end:
         g.set_option(k, v)
     for ov in sys.argv[3:]:                          # NAME=VALUE options for every handle (A/B of a default)
         g.set_option(ov.split("=")[0], int(ov.split("=")[1]))
+    mixed = prec == 64 and rng.integers(0, 5) == 0   # one fp64 handle in five with the inverse in fp32 (option
+    if mixed:                                        # gradient_precision = 32): LML / mu / sigma bounds stay fp64's
+        g.set_option("gradient_precision", 32)
     tol = {"lml": 1e-8, "grad": 1e-6, "mu": 1e-6, "sigma": 1e-5} if prec == 64 else \
           {"lml": 3e-4, "grad": 3e-3, "mu": 3e-2, "sigma": 3e-3}  # fp32: errors follow the conditioning.  Round 3
                                                                    # widened grad to 1e-2 for seed 7 (matern32, n = 1721,
                                                                    # D = 2: 3.6e-3, all in the scale component); round 4
                                                                    # takes that component from its closed form: back to 3e-3
+    if mixed:
+        # the reference's own gradient tolerance (gp_test.go:170,248) for kernels with ONE term, whose cancelling
+        # components come from closed forms; sums of terms have no closed form per term: 1.9e-4 seen (hyperpriors, n = 1365)
+        tol = dict(tol, grad=1e-4 if len(getattr(simil, "terms", [simil])) == 1 and name not in ("hyperpriors", "periodic_sum") else 1e-3)
     o = FastOracle(D, simil, noise)
     for rep in range(int(rng.integers(1, 5))):       # the same handle with changing data sizes
         n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
@@ -47,7 +55,7 @@ while time.time() < t_end:
         grad = g.Gradient()
         if order == 2:
             grad = g.Gradient()                      # Gradient twice
-        if prec == 64 and "lookahead" not in opts and "eager" not in opts and rng.integers(0, 3) == 0:
+        if prec == 64 and not mixed and "lookahead" not in opts and "eager" not in opts and rng.integers(0, 3) == 0:
             # the same point plus perturbed ones as candidates of one launch sequence: bit-equal,
             # and the handle's own state (checked by Produce below) untouched
             kc = int(rng.integers(1, 6))
@@ -63,9 +71,11 @@ while time.time() < t_end:
              "grad": np.abs(grad - grad_o).max() / max(1.0, np.abs(grad_o).max()),
              "mu": np.abs(mu - mu_o).max() / max(1e-12, np.abs(mu_o).max()),
              "sigma": np.nanmax(np.abs(sigma - sigma_o)) / max(1e-12, np.nanmax(np.abs(sigma_o)))}
-        if prec == 64:
+        if prec == 64 and not mixed:
             for k in e:
                 worst[k] = max(worst[k], float(e[k]))
+        if mixed:
+            worst_mixed = max(worst_mixed, float(e["grad"]))
         if any(e[k] > tol[k] for k in tol):
             print("MISMATCH", name, n, opts, order, "precision", prec, e, flush=True)
             np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
@@ -81,5 +91,5 @@ while time.time() < t_end:
         if nrun % 100 == 0:
             print("  ... %d evaluations OK, %.0f s left" % (nrun, t_end - time.time()), flush=True)
     g.close()
-print("stress: %d evaluations OK in %.0f s; worst relative errors fp64 %s; fp32 path %s" % (
-    nrun, seconds, worst, worst32), flush=True)
+print("stress: %d evaluations OK in %.0f s; worst relative errors fp64 %s; fp32 path %s; gradient_precision = 32: grad %.3e" % (
+    nrun, seconds, worst, worst32, worst_mixed), flush=True)
