@@ -209,3 +209,30 @@ def test_roofline_is_recomputable_from_the_tracked_trace():
     traffic = json.load(open(os.path.join(prof, rnd + "_pmc_traffic.json")))
     assert line["library"].endswith("build " + traffic["build"])
     assert abs(line["roofline"]["traffic"] - traffic["3"]["bytes_per_launch"]) < 1.0
+
+
+def test_tracked_bench_line_carries_the_contract_fields():
+    """The newest tracked default-configuration line (profiles/rNN_bench_c3.json) is BASELINE.json's metric on its
+    headline configuration with the two objects the measurement contract asks for, the Produce roofline and -- clearly
+    apart from `value` -- the mixed-precision option."""
+    import json
+    line = json.load(open(_newest_profile("bench_c3.json")))
+    assert line["metric"].startswith("GP.Observe+Gradient evals/sec (fp64) at N=16384 D=8")
+    assert line["dtype"] == "f64" and line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["config"]["candidates_per_step"] == 1 and "configs[2]" in line["config"]["workload"]
+    assert abs(line["value"] - 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 78.6 and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac_wall"] <= r["frac"] < 1.0
+    assert abs(r["frac_wall"] - 16384.0 ** 3 / (line["ms_per_step"] * 1e-3) / 78.6e12) < 1e-9
+    assert r["traffic"] and r["traffic"] > 1e8
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert line["lml_rel_err_vs_oracle"] < 1e-6 and line["mu_rel_err_vs_oracle"] < 1e-6 and line["sigma_rel_err_vs_oracle"] < 1e-6
+    p = line["produce"]
+    assert p["m"] == 1024 and abs(p["roofline"]["frac"] - 16384.0 ** 2 * 1024 / (p["ms_per_call"] * 1e-3) / 78.6e12) < 1e-9
+    assert [q["m"] for q in p["m_sweep"]] == [1, 64, 8192]
+    m = line["mixed_precision_gradient"]  # an option beside the value, never the value
+    assert m["lml_identical_to_native"] is True and m["grad_rel_diff_vs_native"] < 1e-6
+    assert m["evals_per_s"] > line["value"] and "not `value`" in m["note"]
+
