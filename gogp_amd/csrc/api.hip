@@ -788,10 +788,16 @@ static int factorize_t(gogp_handle *h, bool eager) {
     (void)gogp::rec_stream_wait(sp, ev(h, EV_KINV));
     h->kinv_pending = false;
   }
+  if (h->kinv_c1 > 0 && !h->have_kinv) {
+    // ... or the first of K^-1's two launches (option "kinv_split") that no Gradient picked up
+    (void)gogp::rec_stream_wait(s, ev(h, EV_KINV));
+    (void)gogp::rec_stream_wait(sp, ev(h, EV_KINV));
+  }
   h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
   h->alpha_pending = false;
   h->trtri_done = false;
   h->notpd = -1;
+  h->kinv_c1 = 0;
   // option "kinv_fused": -1 (default) fuses up to npad = 10240 (measured: N = 1024 .. 8192 5-10 % faster,
   // N = 16384 1.7 % slower than one LAUUM launch over the finished Y, which runs at the longest K)
   // (the mixed gradient fuses at every size: its rank-k updates are fp32 and fill CUs the fp64 Cholesky chain leaves
@@ -924,6 +930,20 @@ static int factorize_t(gogp_handle *h, bool eager) {
         mixed_superstep(h, P0, nsub, prevP0, next_nsub, st, s2, fuse_kinv);
       else
         trtri_superstep<T>(h, own_bufs<T>(h), P0, nsub, prevP0, next_nsub, st, s2);
+      if (std::is_same<T, double>::value && !fuse_kinv && !mixed && !h->batch_mode && h->kinv_split > 0 &&
+          h->kinv_c1 == 0 && CE < npad && CE * 100 >= npad * (int64_t)h->kinv_split) {
+        // ---- option "kinv_split" (sizes above the fused ones): the part of K^-1 = Y Y^T that the finished column
+        // panels of Y determine -- K^-1[0:CE, 0:CE] = sum over k < CE -- as ONE ragged-K launch now, at the lowest
+        // priority, into the dead corner of bufA (as the fused updates below); Gradient's launch then only sums
+        // k >= CE on top of it, in the same order of k: bit-identical.  N = 16384, alternating runs on one box:
+        // 71.98-72.19 ms without, 71.65-71.85 with 60 % (50 %: 71.8, 30-40 %: 72.0, 80 %: 71.75, 90 %: 72.2);
+        // N = 32768: no difference (547.5 / 550.7 against 550.0 / 547.6).
+        (void)gogp::rec_stream_wait(h->sk, ev(h, EV_BASE + 4 * P0 + 2));
+        const T *Y0 = reinterpret_cast<const T *>(h->bufY);
+        launch_gemm_nt(h->sk, GEMM_LAUUM, (int)(CE / TILE), (int)(CE / TILE), CE, 1.0, Y0, ld, Y0, ld, 0.0, A, ld, pf);
+        (void)gogp::rec_event_record(ev(h, EV_KINV), h->sk);
+        h->kinv_c1 = CE;
+      }
       if (fuse_kinv && !mixed) {
         // ---- and K^-1 = Y Y^T = sum over the column panels of Y, right behind: the rank-(nsub*256)
         // update K^-1[0:CE, 0:CE] (+)= Y[0:CE, C0:CE] Y[0:CE, C0:CE]^T on the lower tiles (block rows
@@ -1178,11 +1198,17 @@ static int compute_kinv_t(gogp_handle *h) {
     (void)gogp::rec_stream_wait(s, ev(h, h->ydone_valid ? EV_YDONE : EV_TRTRI));
   }
   // K^-1 (lower tiles) = Y Y^T, ragged K range; the Cholesky work area is dead, write over it
-  if (mixed)
+  if (mixed) {
     launch_gemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, h->g32Y, ld, h->g32Y, ld, 0.0, h->g32A, ld, pf);
-  else
+  } else {
+    GemmGrid gk;
+    if (h->kinv_c1 > 0) {  // the sweep launched the sums over k < kinv_c1 (factorize_t)
+      (void)gogp::rec_stream_wait(s, ev(h, EV_KINV));
+      gk.kbeg0 = (int)h->kinv_c1;
+    }
     launch_gemm_nt(s, GEMM_LAUUM, h->nblk, h->nblk, npad, 1.0, reinterpret_cast<const T *>(h->bufY), ld,
-                   reinterpret_cast<const T *>(h->bufY), ld, 0.0, reinterpret_cast<T *>(h->bufA), ld, pf);
+                   reinterpret_cast<const T *>(h->bufY), ld, 0.0, reinterpret_cast<T *>(h->bufA), ld, pf, &gk);
+  }
   // whatever follows on s is ordered behind ALL of the inverse's chain stream
   if (h->trtri_pending && h->ydone_valid) (void)gogp::rec_stream_wait(s, ev(h, EV_TRTRI));
   h->trtri_pending = false;
@@ -2197,6 +2223,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
       h->have_data = h->factored = h->have_alpha = h->have_kinv = h->observed = h->grad_valid = false;
       h->trtri_done = h->trtri_pending = h->alpha_pending = h->kinv_pending = false;
     }
+    return GOGP_OK;
+  }
+  if (strcmp(name, "kinv_split") == 0) {  // percent of the columns of Y whose part of K^-1 is launched inside the sweep; 0: off
+    if (value < 0 || value > 95) return fail(h, GOGP_EARG, "kinv_split must be 0..95");
+    h->kinv_split = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "kinv_fused") == 0) {  // -1: by size (default), 0: LAUUM in Gradient, 1: fused

@@ -91,6 +91,9 @@ struct GemmGrid {
   // up to ~3000 tiles (820 tiles at K = 768: 61 against 51 TFLOP/s); inside an evaluation, beside other streams'
   // launches, it loses -- so only Produce, which runs alone, raises it.
   int small_below = 384;
+  // GEMM_LAUUM in two launches (api.hip: option "kinv_split"): tile (ti, tj) sums k >= max(ti * 128, kbeg0) and the
+  // tile rows above kbeg0 ACCUMULATE into C (the first launch, K = kbeg0, left their sums over k < kbeg0 there)
+  int kbeg0 = 0;
 };
 
 // Local <-> global index map of the 2-D block-cyclic layout: distribution blocks of

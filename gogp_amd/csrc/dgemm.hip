@@ -60,6 +60,7 @@ struct GemmArgs {
   int ktri;      // GEMM_RECT: B lower triangular, tile column tj sums k < (tj + 1) * BT only
   int prio;      // chain launch: s_setprio 3 (common.h: GemmGrid)
   int krag0;     // RECT / LOWER: tile rows ti >= krag0 start at k = (ti - krag0) * BT (common.h: GemmGrid); INT_MAX: none
+  int kbeg0;     // GEMM_LAUUM: second of two launches (common.h: GemmGrid)
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
 };
 
@@ -191,6 +192,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   }
   if (MODE == GEMM_LAUUM) {
     kbeg = ti * BT;
+    if (kbeg < g.kbeg0) {  // the first launch summed k < kbeg0 into this tile
+      kbeg = g.kbeg0;
+      beta = 1.0;
+    }
     nkt = (g.kend - kbeg) / GEMM_BK;
     if (nkt <= 0) return;  // whole-workgroup exit (tile-uniform)
   }
@@ -343,6 +348,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   g.ktri = (mode == GEMM_RECT && grid && grid->ktri) ? 1 : 0;
   g.prio = grid ? grid->prio : 0;
   g.krag0 = (mode != GEMM_LAUUM && mode != GEMM_TRAP && grid && grid->krag0 >= 0 && !g.ktri) ? grid->krag0 : 0x7fffffff;
+  g.kbeg0 = (mode == GEMM_LAUUM && grid) ? grid->kbeg0 : 0;
   g.bstride = tl_batch.stride;
   const unsigned nz = (unsigned)tl_batch.k;
   if (grid && grid->rule) {
@@ -399,7 +405,7 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     } else {
       flops = 0;
       for (int i = 0; i < mt; ++i)
-        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - (int64_t)i * TILE);
+        flops += 2.0 * (double)(i + 1) * TILE * TILE * (double)(K - std::max<int64_t>((int64_t)i * TILE, g.kbeg0));
     }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -110,6 +110,8 @@ struct gogp_handle {
   int krag = 1;                // the inverse's updates skip the zero triangle of a super-panel of Y (common.h: GemmGrid::krag0)
   int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the
                                // gradient on the matrix cores (grad_mfma.hip); 65: never
+  int kinv_split = 60;         // percent of the columns whose part of K^-1 = Y Y^T is launched DURING the sweep (api.hip; 0: off)
+  int64_t kinv_c1 = 0;         // ... columns that launch covered in the current factorisation (0: none)
   int kinv_fused = -1;          // ... and accumulates K^-1 = sum_P Y_P Y_P^T behind it, one rank-k update
                                // per super-panel of Y (0: one LAUUM launch over the finished Y in Gradient; -1: by size)
   int inv_prio = 0;            // 0: the inverse's streams at normal priority; 1: its bulk updates (s2) low;

@@ -351,6 +351,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "kinv_fused"   -1|0|1  K^-1 accumulated behind the triangular inverse as one rank-k update per
  *                          super-panel of Y (1) or formed by one launch over the finished Y in
  *                          gogp_gradient (0); -1: fused up to N = 10240                    (default -1)
+ *   "kinv_split"   0..95   where K^-1 is not fused (fp64, N > 10240): once this percentage of the columns of Y is
+ *                          final, their part of K^-1 = Y Y^T is one launch inside the sweep and gogp_gradient's launch
+ *                          adds the rest (same sums, same order: bit-identical); 0: one launch       (default 60)
  *   "chain_prio"   -1..2   the chains' tile-kernel launches raise their waves' issue priority: 0 never, 1 the
  *                          skinny (64x64-tile) ones, 2 all of them, -1 the skinny ones up to N = 6144  (default -1)
  *   "ktri"         1 | 0   panel solves skip the zero half of the (lower triangular) block inverse (default 1)

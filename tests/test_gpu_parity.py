@@ -445,6 +445,30 @@ def test_produce_through_superpanel_inverses_matches_panel_substitution(gpmod, n
     g.close()
 
 
+def test_kinv_in_two_launches_is_bit_identical(gpmod):
+    """Above the sizes whose K^-1 accumulates inside the sweep (npad > 10240) the first 60 % of the columns' part of
+    K^-1 = Y Y^T is launched during the sweep and Gradient's launch adds the rest (api.hip: option kinv_split): the
+    same sums in the same order.  Also: a factorisation whose early launch no Gradient picks up must not disturb the
+    next one."""
+    rng = np.random.default_rng(77)
+    n, D = 10400, 3
+    X, y = _data(rng, n, D)
+    x = np.log([1.1, 0.6, 0.1])
+    g = gpmod.GP(D, kernel.Scaled(kernel.Matern52), kernel.UniformNoise, X=X, Y=y)
+    g.set_option("kinv_split", 0)
+    g.Observe(x)
+    lml0, g0 = g.LML(), g.Gradient().copy()
+    for pct in (60, 30, 90):
+        g.set_option("kinv_split", pct)
+        g.Observe(x)
+        assert g.LML() == lml0
+        np.testing.assert_array_equal(g.Gradient(), g0)
+    g.Observe(x + 0.1)   # nobody asks for this gradient
+    g.Observe(x)
+    np.testing.assert_array_equal(g.Gradient(), g0)
+    g.close()
+
+
 def test_not_positive_definite(gpmod):
     """Duplicate inputs with zero noise: Factorize fails (gp/gp.go:228-230)."""
     X = np.array([[0.0], [0.0], [1.0]])
