@@ -28,8 +28,11 @@
 // (wg_gemm128); B is staged once per workgroup through LDS, the Schur product reads both
 // operands from S.
 //
-// Timing (tools/diag_probe.py, cycles of s_memtime at 2.36 GHz): 2 x 69K factor, 2 x 22K
-// inverse, 4 products 28-36K each incl. epilogues, 18K plain copies = 144 us per block.
+// Timing (tools/diag_probe.py, cycles of s_memtime; round 4): 2 x 55.6K factor (seven 16-column steps of 6.7-8.4K:
+// sixteen dependent pivot columns of ~360 cycles each -- v_rsq_f64, two Newton steps, the scaled pivot row's
+// v_readlane, the next pivot's update: ~11 dependent fp64 operations per column -- plus the eight 16x16 inverses),
+// 2 x 22K inverse, products 27-34K each incl. epilogues (the MFMA issue alone is ~18K: their eight accumulator chains
+// per wave wait for LDS fragments), 19K plain copies = 301K cycles = 128 us per block.
 //
 // LDS: S[128][130] doubles (padding 2 => the MFMA fragment reads of 16 rows x
 // 2 k hit 64 distinct banks), G = 2304 doubles: the eight 16x16 inverses during the factor /
@@ -134,28 +137,28 @@ __device__ __forceinline__ void panel16_store_diag(double *S, int kb, double *ri
   }
 }
 
-// Inverse of the 16x16 lower-triangular diagonal block kb of S by ONE wave (lane c
-// owns column c, forward substitution with v_readlane broadcasts of the rows).
+// Inverse of the 16x16 lower-triangular diagonal block kb of S by ONE wave: lane c owns column c of X = L^-1 and runs
+// the forward substitution against e_c.  The coefficients L[rr][q] are the same for every lane: each row is ONE
+// broadcast read from LDS (every lane the same address: no bank conflict).  (Until round 4 they were v_readlane
+// broadcasts of the lanes' own rows: 240 SGPRs at once -- hipcc hoisted them all and spilled every one into VGPR lanes
+// and back, 2 x 148 of the kernel's 456 SGPR spills; same operations in the same order: bit-identical results.)
 // HAVE_RINV: 1/L_jj is already in rinv[]; otherwise it is formed here.
 template <bool HAVE_RINV>
 __device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, const double *rinv,
                                       int lane) {
   const int r = lane & 15;
-  double a[16];
-  const double *src = S + (kb * 16 + r) * SLD + kb * 16;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) a[c] = src[c];
+  const double *Lb = S + (kb * 16) * SLD + kb * 16;
   double x[16];
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     double s = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
-    for (int q = 0; q < rr; ++q) s -= readlane_d(a[q], rr) * x[q];
+    for (int q = 0; q < rr; ++q) s -= Lb[rr * SLD + q] * x[q];
     double ri;
     if (HAVE_RINV) {
       ri = rinv[rr];
     } else {
-      const double d = readlane_d(a[rr], rr);
+      const double d = Lb[rr * SLD + rr];
       ri = __builtin_amdgcn_rcp(d);
       ri = fma(ri, fma(-d, ri, 1.0), ri);
       ri = fma(ri, fma(-d, ri, 1.0), ri);
@@ -399,44 +402,58 @@ __device__ void wg_gemm128(f64x4 (&c)[2][4], const double *S, double *G, const d
     __syncthreads();  // every wave is done reading S
     return;
   }
-  double2 pre = *reinterpret_cast<const double2 *>(gp);
-  G[so] = pre.x;
-  G[so + 1] = pre.y;
+  // Chunk c travels global -> registers (slot c & 3, requested FOUR chunks before its use: an L2 round trip is about as
+  // long as one chunk's MFMAs, so with the request only one chunk ahead -- until round 4 -- every chunk waited for its
+  // data: 28-32K cycles per product against 16K of MFMA issue) -> LDS buffer c & 1 (written while chunk c - 1 is
+  // multiplied) -> fragments.
+  constexpr int NCH = 128 / BCH, PD = 4;
+  static_assert(NCH % PD == 0, "the chunk loop is unrolled by the prefetch depth");
+  double2 pre[PD];
+  pre[0] = *reinterpret_cast<const double2 *>(gp);
+#pragma unroll
+  for (int u = 1; u < PD; ++u) pre[u] = *reinterpret_cast<const double2 *>(gp + (long)u * gstep);
+  G[so] = pre[0].x;
+  G[so + 1] = pre[0].y;
   __syncthreads();
 #pragma unroll 1
-  for (int kc = 0; kc < 128 / BCH; ++kc) {
-    const bool more = kc + 1 < 128 / BCH;
-    if (more) pre = *reinterpret_cast<const double2 *>(gp + (long)(kc + 1) * gstep);
-    const double *bs = G + (kc & 1) * BBUF + bo;
-    // first active column tile (TRI_B: ct(n) needs kc >= 2 ct(n))
-    int nb = 0;
-    if (TRI == TRI_B) {
-      const int h = kc / 2 - wc;                 // 2n <= h
-      nb = h < 0 ? 0 : min(4, h / 2 + 1);        // column tiles n < nb are active
-    }
-    const bool act0 = kc < e0, act1 = kc < e1;
-    if (act0 || act1) {
+  for (int kc0 = 0; kc0 < NCH; kc0 += PD) {
 #pragma unroll
-      for (int k4 = 0; k4 < BCH / 4; ++k4) {
-        const double a0 = ap0[kc * BCH + k4 * 4];
-        const double a1 = ap1[kc * BCH + k4 * 4];
-        double b[4];
+    for (int u = 0; u < PD; ++u) {
+      const int kc = kc0 + u;
+      const bool more = kc + 1 < NCH;
+      // slot u held chunk kc, which went to LDS one step ago
+      if (kc + PD < NCH) pre[u] = *reinterpret_cast<const double2 *>(gp + (long)(kc + PD) * gstep);
+      const double *bs = G + (kc & 1) * BBUF + bo;
+      // first active column tile (TRI_B: ct(n) needs kc >= 2 ct(n))
+      int nb = 0;
+      if (TRI == TRI_B) {
+        const int h = kc / 2 - wc;                 // 2n <= h
+        nb = h < 0 ? 0 : min(4, h / 2 + 1);        // column tiles n < nb are active
+      }
+      const bool act0 = kc < e0, act1 = kc < e1;
+      if (act0 || act1) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = bs[n * BN + k4 * BS];
+        for (int k4 = 0; k4 < BCH / 4; ++k4) {
+          const double a0 = ap0[kc * BCH + k4 * 4];
+          const double a1 = ap1[kc * BCH + k4 * 4];
+          double b[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const bool on = (TRI == TRI_B) ? n < nb : true;
-          if (on && act0 && n < n0) c[0][n] = mfma(a0, b[n], c[0][n]);
-          if (on && act1 && n < n1) c[1][n] = mfma(a1, b[n], c[1][n]);
+          for (int n = 0; n < 4; ++n) b[n] = bs[n * BN + k4 * BS];
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const bool on = (TRI == TRI_B) ? n < nb : true;
+            if (on && act0 && n < n0) c[0][n] = mfma(a0, b[n], c[0][n]);
+            if (on && act1 && n < n1) c[1][n] = mfma(a1, b[n], c[1][n]);
+          }
         }
       }
+      if (more) {
+        double *d = G + ((kc + 1) & 1) * BBUF + so;
+        d[0] = pre[(u + 1) % PD].x;
+        d[1] = pre[(u + 1) % PD].y;
+      }
+      __syncthreads();  // chunk kc+1 visible; everybody done with chunk kc (and, at the end, with S)
     }
-    if (more) {
-      double *d = G + ((kc + 1) & 1) * BBUF + so;
-      d[0] = pre.x;
-      d[1] = pre.y;
-    }
-    __syncthreads();  // chunk kc+1 visible; everybody done with chunk kc (and, at the end, with S)
   }
 }
 

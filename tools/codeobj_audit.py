@@ -28,12 +28,13 @@ SGPR_SPILL_LIMIT = 48
 SGPR_SPILL_ALLOW = {
     # the chain's diagonal-block kernel with potrf128_lds inlined: measured 7 % faster than the out-of-line
     # call hipcc chooses by itself (313,996 vs 336,912 cycles per 256-block), which also needs a 20-byte
-    # private segment for the callee-saved VGPRs; the spilled SGPRs are hoisted LDS offsets of the unrolled
-    # 16-column steps
-    r"diag256_kernel<true, false, \d+>": 480,
-    r"diag256_wait_kernel<\d+>": 480,  # the same body behind the input-flag poll (option diag_early)
-    # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor
-    r"diag256_kernel<false, false, \d+>": 260,
+    # private segment for the callee-saved VGPRs.  Round 4: 456 -> 140 (the 16x16 inverses read their coefficients
+    # as LDS broadcasts instead of 240 v_readlane results that hipcc hoisted and spilled); what is left are the
+    # sixteen lane == j masks of panel16 (hoisted out of the column-block loop) and kernel arguments
+    r"diag256_kernel<true, false, \d+>": 160,
+    r"diag256_wait_kernel<\d+>": 160,  # the same body behind the input-flag poll (option diag_early)
+    # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor (round 4: 248 -> 6)
+    r"diag256_kernel<false, false, \d+>": 48,
     # multi-term / periodic kernels keep the per-pair loop: kind, scale, period and length tables of up to
     # four terms stay live across it.  Not on any BASELINE configuration (those are single radial terms)
     r"grad_reduce_kernel<\d+, (true|false), (double|float), false>": 80,
