@@ -362,9 +362,11 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          cores (grad_mfma.hip); 65: never                                 (default 1)
  *   "graph"        0..2    gogp_observe_gradient_candidates: on its second identical use the launch sequence
  *                          becomes a hipGraph and is replayed (parameters and data may change, sizes may not).
- *                          1: an explicitly built graph -- one node per launch / copy, the sweep's real
- *                          cross-stream dependencies as edges, no stream capture -- up to N = 8192;
- *                          2: round 2's linear graph from stream capture, N <= 1024; 0: streams (default 1)
+ *                          1: round 2's linear graph from stream capture, N <= 1024 (larger sizes: streams);
+ *                          2: an explicitly built graph -- one node per launch / copy, the sweep's real
+ *                          cross-stream dependencies as edges, no stream capture -- up to N = 8192:
+ *                          bit-identical to the stream path and, on this runtime, slower than it (DESIGN.md
+ *                          section 4); 0: streams                                           (default 1)
  *   "produce_tinv", "produce_panels", "produce_groups", "produce_small_below"
  *                          gogp_produce: whole super-panels of `produce_panels` 256-column panels solved through
  *                          the inverse of the factor's diagonal block (1) or panel by panel (0); the test
