@@ -437,8 +437,13 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // ranges are cut at 128-row granularity).  Launches of >= 3072 tiles and LAUUM use the
   // 8-wave shape of the 128x128 tile (measured 4-9 % faster there), the rest the 4-wave one.
   // (a batched launch counts the tiles of all its candidates: together they fill the chip)
+  // ... and so do launches of 513 .. 768 tiles: 128 x 128 tiles have 512 places on the chip (two per CU), so such a
+  // launch runs a second, almost empty round at the full per-round price (528 tiles at K = 512, the last fused K^-1
+  // update of an N = 4096 evaluation: 203 us); as 64 x 64 tiles it is two rounds of a quarter of the work each
+  // (one N = 4096 evaluation 3.54-3.59 -> 3.48-3.50 ms; N = 16384 and 8 candidates at N = 4096 unchanged)
   const long total_tiles = (long)ntiles * nz;
-  const bool small = (mode != GEMM_LAUUM) && (total_tiles < (grid ? grid->small_below : 384));
+  const bool small = (mode != GEMM_LAUUM) && (total_tiles < (grid ? grid->small_below : 384) ||
+                                              (total_tiles > 512 && total_tiles <= 768));
   // chain_prio = 1: only the skinny launches (64x64 tiles) raise their priority; 2: every chain launch
   if (g.prio == 1 && !small) g.prio = 0;
   if (small) {
