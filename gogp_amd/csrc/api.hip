@@ -97,6 +97,9 @@ static void free_n_buffers(gogp_handle *h) {
   (void)hipFree(h->rz);
   (void)hipFree(h->rd);
   (void)hipFree(h->rpart);
+  (void)hipFree(h->small_ws);
+  h->small_ws = nullptr;
+  h->small_ws_bytes = 0;
   (void)hipFree(h->TX);
   (void)hipFree(h->Tmt);
   h->TX = h->Tmt = nullptr;
@@ -118,6 +121,8 @@ static void free_n_buffers(gogp_handle *h) {
 static void drop_cand_graph(gogp_handle *h) {
   if (h->cand_graph) (void)hipGraphExecDestroy(h->cand_graph);
   h->cand_graph = nullptr;
+  // "captured on its second identical use" starts over: what was seen was seen under the old options / buffers
+  h->cand_seen_key = decltype(h->cand_seen_key)();
 }
 // the capture / replay stream belongs to the handle's pooled stream set (streams are never destroyed,
 // see "stream sets" below): created on first use, handed on with the set
@@ -1063,15 +1068,14 @@ static int ensure_alpha(gogp_handle *h) {
 }
 
 static int set_theta_natural(gogp_handle *h, const double *ts, const double *tn) {
-  for (int i = 0; i < h->ns; ++i) {
+  // validate everything first: a refused vector leaves the handle's parameters as they were
+  for (int i = 0; i < h->ns; ++i)
     if (!(ts[i] > 0.0) || !std::isfinite(ts[i]))
       return fail(h, GOGP_EARG, "similarity parameters must be positive and finite");
-    h->theta_s[i] = ts[i];
-  }
-  for (int i = 0; i < h->nn; ++i) {
+  for (int i = 0; i < h->nn; ++i)
     if (!std::isfinite(tn[i])) return fail(h, GOGP_EARG, "noise parameter must be finite");
-    h->theta_n[i] = tn[i];
-  }
+  for (int i = 0; i < h->ns; ++i) h->theta_s[i] = ts[i];
+  for (int i = 0; i < h->nn; ++i) h->theta_n[i] = tn[i];
   return GOGP_OK;
 }
 
@@ -1444,20 +1448,28 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     // the LAST candidate's factorisation (as after gogp_observe of it) -- unlike the single-GPU form, which leaves
     // the handle's own state alone.
     HIPCHK(h, hipSetDevice(h->device));
+    // the per-candidate contract of include/gogp_hip.h holds here too: every lml / gradient / status slot is written
+    // before anything can fail, and a candidate with unusable parameters (GOGP_EARG: every rank sees the same
+    // candidates, so every rank skips it) or a matrix that is not positive definite only marks its own slot
+    for (int c = 0; c < k; ++c) {
+      lmls[c] = NAN;
+      if (status) status[c] = GOGP_ESTATE;  // "not evaluated": overwritten below unless the call aborts
+      for (int64_t i = 0; i < len; ++i) grads[(size_t)c * len + i] = 0.0;
+    }
     int first_d = GOGP_OK;
     for (int c = 0; c < k; ++c) {
       double *g = grads + (size_t)c * len;
-      for (int64_t i = 0; i < len; ++i) g[i] = 0.0;
-      lmls[c] = NAN;
       h->with_obs = false;
       int r = observe_theta(h, xs + (size_t)c * len, &lmls[c]);
       if (r == GOGP_OK || r == GOGP_ECOND) {
         const int rg = gogp_gradient(h, g, len);
         if (rg != GOGP_OK) r = rg;
-      } else if (r == GOGP_ENOTPD) {
+      }
+      if (r == GOGP_ENOTPD || r == GOGP_EARG) {
         lmls[c] = NAN;
-      } else {
-        return r;  // a transport / HIP failure: nothing after it can be trusted
+        for (int64_t i = 0; i < len; ++i) g[i] = 0.0;
+      } else if (r != GOGP_OK && r != GOGP_ECOND) {
+        return r;  // a transport / HIP failure: nothing after it can be trusted (the later slots stay GOGP_ESTATE)
       }
       if (status) status[c] = r;
       if (first_d == GOGP_OK && r != GOGP_OK) first_d = r;
@@ -1878,6 +1890,43 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
   launch_rownorm_dot(s, V, ld, nullptr, npad, m, nullptr, dq);
 }
 
+// Few test points (option "produce_small_max", default 64; fp64 matrices): Kstar, the mean, and V = L^-1 Kstar by the
+// persistent substitution kernel of trsm_small.hip -- one pass over the factor (8 N^2 / 2 bytes) instead of the
+// ~36-launch GEMM chain.  The reference's forecast harness asks for ONE point per step (tutorial/tutorial.go:178-179).
+static int produce_small(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad, double *dmu, double *dq) {
+  const int64_t npad = h->npad, ld = npad;
+  const size_t one = (trsm_small_workspace_bytes(std::max(npad, h->cap_npad)) + 255) / 256 * 256;
+  const size_t need = 2 * one;  // 33 .. 64 points: two launches of <= 32 columns side by side
+  if (!h->small_ws || h->small_ws_bytes < need) {
+    (void)hipFree(h->small_ws);
+    h->small_ws = nullptr;
+    h->small_ws_bytes = 0;
+    HIPCHK(h, hipMalloc(&h->small_ws, need));
+    h->small_ws_bytes = need;
+  }
+  {
+    AuxTimer tm(h, GOGP_PROF_CROSS, s);
+    launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, h->KsT, ld);  // gp/gp.go:322-332
+  }
+  launch_rownorm_dot(s, h->KsT, ld, h->alpha, npad, m, dmu, nullptr);  // mean = Kstar^T alpha (gp/gp.go:335)
+  unsigned *tmo = nullptr, *tmo2 = nullptr;
+  unsigned *htmo = reinterpret_cast<unsigned *>(h->hscal + 10);
+  htmo[0] = htmo[1] = 0;
+  const int m1 = (int)std::min<int64_t>(m, 32);
+  const size_t ev0 = EV_BASE + 4 * (size_t)(npad / PANEL) + 8;  // Produce's event slots behind the factorisation's own
+  if (m > 32) {
+    // the second 32 columns on a second stream, beside the first (both launches read the same factor at the same
+    // time: what one pulls into the Infinity Cache the other finds there)
+    order(h, ev0 + 1, s, h->s2);
+    launch_trsm_small(h->s2, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 32, (int)m - 32, (char *)h->small_ws + one, dq, &tmo2);
+    HIPCHK(h, hipMemcpyAsync(htmo + 1, tmo2, sizeof(unsigned), hipMemcpyDeviceToHost, h->s2));
+  }
+  launch_trsm_small(s, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 0, m1, h->small_ws, dq, &tmo);
+  HIPCHK(h, hipMemcpyAsync(htmo, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  if (m > 32) order(h, ev0 + PRODUCE_GROUPS + 1, h->s2, s);
+  return GOGP_OK;
+}
+
 extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *mu,
                             double *sigma) {
   if (!h || m < 0 || (m > 0 && (!Z || !mu || !sigma))) return fail(h, GOGP_EARG, "produce: NULL");
@@ -1907,7 +1956,11 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   }
   rc = ensure_alpha(h);
   if (rc != GOGP_OK) return rc;
-  if (h->prec == 32)
+  const bool small = h->prec == 64 && m <= h->produce_small_max;
+  if (small) {
+    rc = produce_small(h, s, m, mpad, dmu, dq);
+    if (rc != GOGP_OK) return rc;
+  } else if (h->prec == 32)
     produce_solve_t<float>(h, s, m, mpad, dmu, dq);
   else
     produce_solve_t<double>(h, s, m, mpad, dmu, dq);
@@ -1916,6 +1969,15 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   HIPCHK(h, hipMemcpyAsync(sigma, dsig, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  if (small && (reinterpret_cast<const unsigned *>(h->hscal + 10)[0] | reinterpret_cast<const unsigned *>(h->hscal + 10)[1]) != 0u) {
+    // a workgroup of the persistent substitution gave up waiting for another one (trsm_small.hip): the numbers are
+    // not to be trusted -- say so instead of returning them
+    char buf[160];
+    snprintf(buf, sizeof buf, "Produce: the substitution kernel timed out waiting for a workgroup (code 0x%x)",
+             reinterpret_cast<const unsigned *>(h->hscal + 10)[0] | reinterpret_cast<const unsigned *>(h->hscal + 10)[1]);
+    h->err = buf;
+    return GOGP_EHIP;
+  }
   return GOGP_OK;
 }
 
@@ -2173,6 +2235,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "produce_small_below") == 0) {  // Produce: launches below this many 128-tiles use 64 x 64 tiles
     if (value < 0) return fail(h, GOGP_EARG, "produce_small_below must be >= 0");
     h->produce_small_below = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "produce_small_max") == 0) {  // Produce: up to this many test points through the persistent substitution kernel (0: never)
+    if (value < 0 || value > 64) return fail(h, GOGP_EARG, "produce_small_max must be 0..64");
+    h->produce_small_max = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "produce_groups") == 0) {  // Produce: independent substitution chains over the test points' tile rows

@@ -275,6 +275,13 @@ void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64
 // fp32 path: out[0] = sum_{i<n} alpha_i^2 - |Y|_F^2 (= tr(alpha alpha^T - K^-1)) in fp64 from Y = L^-T; part: n doubles
 void launch_trace_from_y(hipStream_t s, const float *Y, int64_t ld, int64_t n, int64_t npad, const double *alpha,
                          double *part, double *out);
+// trsm_small.hip: V = L^-1 Kstar for the right-hand sides j0 .. j0 + cnt - 1 (rows of KsT, cnt <= 32) in ONE persistent
+// launch that reads the factor once; dq[j] = |V_j|^2.  ws: trsm_small_workspace_bytes(npad) bytes of this launch's own;
+// *tmo_dev: device word that is non-zero afterwards if a workgroup gave up waiting (the caller copies it back and
+// reports GOGP_EHIP)
+size_t trsm_small_workspace_bytes(int64_t npad);
+void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double *Dinv, const double *KsT, int64_t ldk,
+                       int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev);
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b

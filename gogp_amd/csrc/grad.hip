@@ -16,7 +16,6 @@
 namespace gogp {
 
 constexpr int GR_BLOCKS_MAX = 2048;
-constexpr int GR_MAX_ARD_SLOTS = 32;  // the widest instance the launchers use: zero rows behind CjT in LDS
 
 // LOCAL: the tiles are the local ones of a 2-D block-cyclic K^-1 (rectangular nt x ntc tile
 // grid, global row / column indices through `map`, tiles of the global upper triangle skipped).
@@ -228,6 +227,27 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double *__restric
   if (threadIdx.x == 0) out[q] = red[0] + red[1] + red[2] + red[3];
 }
 
+// dynamic LDS of one instance: Ri [64][D], CjT [D + AD][64], ai, aj, red [4][NACC] -- sized per instance (an isotropic
+// kernel at D = 8 asks for 11.8 KB, not for the 32-slot instance's 28 KB: the LDS occupancy ceiling of the hot path)
+static inline size_t gr_lds_bytes(int ndim, int ad) {
+  return (size_t)(128 * ndim + 64 * ad + 128 + 4 * NACC) * sizeof(double);
+}
+// launch one instance; above 64 KB of dynamic LDS (ndim >= 45 with 32 slots) the limit is raised explicitly, as
+// launch_xgrad and grad_mfma.hip do, instead of relying on what the runtime tolerates
+template <int AD, bool LOCAL, class KT, bool R1, class... Args>
+static void gr_launch(dim3 grid, hipStream_t s, int ndim, Args... args) {
+  const size_t lds = gr_lds_bytes(ndim, AD);
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per instance (template): the attribute sticks to the function
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grad_reduce_kernel<AD, LOCAL, KT, R1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gr_lds_bytes(GOGP_MAX_NDIM, AD));
+      raised = true;
+    }
+  }
+  GOGP_KLAUNCH((grad_reduce_kernel<AD, LOCAL, KT, R1>), grid, dim3(256), lds, s, args...);
+}
+
 int grad_reduce_blocks(int64_t npad) {
   const int nt = (int)(npad / 64);
   const long ntiles = (long)nt * (nt + 1) / 2;
@@ -242,7 +262,6 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
   const int ntiles = nt * (nt + 1) / 2;
   const int blocks = grad_reduce_blocks(npad);
   const unsigned nz = (unsigned)tl_batch.k;
-  const size_t lds = (size_t)(128 * ndim + 64 * GR_MAX_ARD_SLOTS + 128 + 4 * NACC) * sizeof(double);
 // More than 16 ARD dimensions: passes of 16 per-dimension accumulators each.  (Instances with 32 / 64
 // accumulators need more than 256 VGPRs; the code hipcc (ROCm 7.2) generates for them -- VGPRs that carry
 // SGPR spill lanes copied through AGPRs -- returned wrong, run-to-run varying sums on the sharded
@@ -250,13 +269,11 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
 #define GOGP_LAUNCH_GR(AD, A0)                                                                    \
   do {                                                                                            \
     if (radial1)                                                                                  \
-      GOGP_KLAUNCH((grad_reduce_kernel<AD, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
-                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
-                         tl_batch.stride);                                                        \
+      gr_launch<AD, false, KT, true>(dim3(blocks, 1, nz), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, \
+                                     partials, 0, BlockMap(), (int)(A0), (long)tl_batch.stride);   \
     else                                                                                          \
-      GOGP_KLAUNCH((grad_reduce_kernel<AD, false, KT, false>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X, \
-                         alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), A0,  \
-                         tl_batch.stride);                                                        \
+      gr_launch<AD, false, KT, false>(dim3(blocks, 1, nz), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, \
+                                      partials, 0, BlockMap(), (int)(A0), (long)tl_batch.stride);  \
   } while (0)
   if (radial1 && ard_dims > 0 && ard_dims >= mfma_min)
     // one radial term, many ARD length scales: distances and per-dimension sums on the matrix cores
@@ -270,14 +287,14 @@ static void grad_reduce_t(hipStream_t s, const DevParams *p, int ndim, int ard_d
     for (int a0 = 0; a0 < ard_dims; a0 += 32) {
       const int left = ard_dims - a0;
       if (left <= 8)
-        GOGP_KLAUNCH((grad_reduce_kernel<8, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
-                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+        gr_launch<8, false, KT, true>(dim3(blocks, 1, nz), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials,
+                                      0, BlockMap(), a0, (long)tl_batch.stride);
       else if (left <= 16)
-        GOGP_KLAUNCH((grad_reduce_kernel<16, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
-                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+        gr_launch<16, false, KT, true>(dim3(blocks, 1, nz), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials,
+                                      0, BlockMap(), a0, (long)tl_batch.stride);
       else
-        GOGP_KLAUNCH((grad_reduce_kernel<32, false, KT, true>), dim3(blocks, 1, nz), dim3(256), lds, s, p, X,
-                           alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, 0, BlockMap(), a0, tl_batch.stride);
+        gr_launch<32, false, KT, true>(dim3(blocks, 1, nz), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials,
+                                      0, BlockMap(), a0, (long)tl_batch.stride);
     }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GR(16, a0);
@@ -308,15 +325,14 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
   const int nt = (int)(mrows / 64), ntc = (int)(ncols / 64);
   const int ntiles = nt * ntc;
   const int blocks = grad_reduce_blocks_local(mrows, ncols);
-  const size_t lds = (size_t)(128 * ndim + 64 * GR_MAX_ARD_SLOTS + 128 + 4 * NACC) * sizeof(double);
 #define GOGP_LAUNCH_GRL(AD, A0)                                                                   \
   do {                                                                                            \
     if (radial1)                                                                                  \
-      GOGP_KLAUNCH((grad_reduce_kernel<AD, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
+      gr_launch<AD, true, KT, true>(dim3(blocks), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, \
+                                    ntc, map, (int)(A0), 0L);                                      \
     else                                                                                          \
-      GOGP_KLAUNCH((grad_reduce_kernel<AD, true, KT, false>), dim3(blocks), dim3(256), lds, s, p, X, alpha, \
-                         Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, A0, 0L);         \
+      gr_launch<AD, true, KT, false>(dim3(blocks), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, \
+                                     ntc, map, (int)(A0), 0L);                                     \
   } while (0)
   if (radial1 && ard_dims > 0 && ard_dims >= mfma_min)
     launch_grad_ard_mfma(s, p, ndim, X, alpha, Kinv, ld, n, nt, ntc, ntiles, blocks, map, partials);
@@ -326,14 +342,14 @@ static void grad_reduce_local_t(hipStream_t s, const DevParams *p, int ndim, int
     for (int a0 = 0; a0 < ard_dims; a0 += 32) {
       const int left = ard_dims - a0;
       if (left <= 8)
-        GOGP_KLAUNCH((grad_reduce_kernel<8, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
-                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+        gr_launch<8, true, KT, true>(dim3(blocks), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map,
+                                     a0, 0L);
       else if (left <= 16)
-        GOGP_KLAUNCH((grad_reduce_kernel<16, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
-                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+        gr_launch<16, true, KT, true>(dim3(blocks), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map,
+                                     a0, 0L);
       else
-        GOGP_KLAUNCH((grad_reduce_kernel<32, true, KT, true>), dim3(blocks), dim3(256), lds, s, p, X, alpha,
-                           Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map, a0, 0L);
+        gr_launch<32, true, KT, true>(dim3(blocks), s, ndim, p, X, alpha, Kinv, (long)ld, (long)n, nt, ntiles, partials, ntc, map,
+                                     a0, 0L);
     }
   } else
     for (int a0 = 0; a0 < ard_dims; a0 += 16) GOGP_LAUNCH_GRL(16, a0);

@@ -61,7 +61,7 @@ struct gogp_handle {
   bool batch_mode = false;      // a batched evaluation is being enqueued (also with k = 1)
   // option "graph": the launch sequence of a batched evaluation captured once into a hipGraph and
   // replayed (the parameters change in pinned host memory only)
-  int use_graph = 1;            // 1: explicitly built graph (graphrec.h), 2: linear graph from stream capture, 0: none
+  int use_graph = 1;            // 1: linear graph from stream capture (N <= 1024; the default), 2: explicitly built DAG (graphrec.h), 0: none
   bool graph_failed = false;    // the runtime refused the explicit graph once: stream path from then on
   int graph_nodes = 0;          // nodes of the graph in use (diagnostics)
   std::string graph_note;
@@ -106,6 +106,11 @@ struct gogp_handle {
   int produce_tinv = 1;                  // option: 0 = Produce substitutes panel by panel (round 3)
   bool tinv_valid = false, tinv_pending = false;  // assembled for the current factor
   int64_t tinv_sig = 0;                  // super-panel layout it was assembled for
+  // Produce for few test points (M <= produce_small_max, fp64, one GPU): ONE persistent launch that reads the factor
+  // once (trsm_small.hip) instead of the tile-kernel chain; 0: off
+  int produce_small_max = 64;
+  void *small_ws = nullptr;    // its workspace (solution / w blocks, counters, partial sums)
+  size_t small_ws_bytes = 0;
   int produce_groups = 2;      // Produce: independent substitution chains (streams) over the test points' tile rows
   int krag = 1;                // the inverse's updates skip the zero triangle of a super-panel of Y (common.h: GemmGrid::krag0)
   int ard_mfma_min = 1;        // ARD kernels (one radial term) with at least this many dimensions reduce the

@@ -291,14 +291,17 @@ class GP:
                                                  ctypes.byref(fl), ctypes.byref(bz)))
         return ms.value, nl.value, fl.value, bz.value
 
-    def observe_gradient_candidates(self, xs):
+    def observe_gradient_candidates(self, xs, strict=True):
         """LML and gradient of k candidate parameter vectors (rows of xs, log theta) on this GP's
         data in ONE launch sequence (gogp_observe_gradient_candidates): what Observe(xs[c]) +
-        Gradient() would return for each c, without touching the GP's own state.  Counterpart:
+        Gradient() would return for each c, without touching the GP's own state (a ShardedGP evaluates
+        them one after the other in its own tiles and afterwards holds the last one's factorisation).  Counterpart:
         candidates evaluated concurrently by the reference's optimiser (optimize.Settings.
         Concurrent, tutorial/tutorial.go:30,141).  Returns (lmls[k], grads[k x P], status[k]):
         a candidate whose matrix is not positive definite has status GOGP_ENOTPD, lml NaN and a
-        zero gradient instead of raising (the other candidates are still valid)."""
+        zero gradient instead of raising (the other candidates are still valid).  strict=False: a candidate
+        with unusable parameters (status GOGP_EARG, e.g. exp(x) overflows) is reported the same way instead of
+        raising -- the C ABI's per-candidate contract, on one GPU and on the shards alike."""
         xs = _arr(xs)
         P = self._ns + self._nn
         xs = xs.reshape(-1, P) if P else xs.reshape(len(xs), 0)
@@ -308,7 +311,7 @@ class GP:
         st = (ctypes.c_int * k)()
         rc = _lib.lib().gogp_observe_gradient_candidates(self._h, k, _dp(xs), P, _dp(lmls), _dp(grads), st)
         status = np.array(list(st), dtype=int)
-        soft = (_lib.GOGP_OK, _lib.GOGP_ENOTPD, _lib.GOGP_ECOND)
+        soft = (_lib.GOGP_OK, _lib.GOGP_ENOTPD, _lib.GOGP_ECOND) + (() if strict else (_lib.GOGP_EARG,))
         if rc not in soft or any(int(v) not in soft for v in status):
             self._check(rc if rc not in soft else _lib.GOGP_EARG)
         return lmls, grads, status

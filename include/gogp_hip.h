@@ -198,7 +198,11 @@ int gogp_observe_gradient_batch(gogp_handle **hs, int k, const double *x, int64_
  * k <= GOGP_MAX_CANDIDATES.  fp64 handle on one GPU: as described.  precision = 32: the candidates pass through
  * ONE arena slot one after the other (same results and the same untouched handle; the float kernels carry no
  * candidate index).  Sharded handle (collective: every rank with the same candidates): evaluated one after the
- * other in the shards' own tiles, and the handle afterwards holds the LAST candidate's factorisation. */
+ * other in the shards' own tiles, and the handle afterwards holds the factorisation of the last candidate that was
+ * factorised (one refused with GOGP_EARG is skipped; after a last candidate that is not positive definite the handle
+ * holds no factorisation).  The per-candidate contract is the same on every kind of handle: all k slots of lmls /
+ * grads / status are written, GOGP_EARG and GOGP_ENOTPD mark their own candidate only; only a transport or HIP
+ * failure ends the call early (status of the candidates not reached: GOGP_ESTATE). */
 #define GOGP_MAX_CANDIDATES 16
 int gogp_observe_gradient_candidates(gogp_handle *h, int k, const double *x, int64_t len,
                                      double *lmls /* k */, double *grads /* k*len */,

@@ -395,6 +395,57 @@ def test_absorb_then_produce_and_restore(gpmod):
     assert abs(g2.LML() - g.LML()) <= 1e-9 * abs(g.LML())
 
 
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3), (300, 1), (700, 1), (1500, 17), (2300, 33), (4096, 64), (5000, 5), (8192, 1)])
+def test_produce_few_points_in_one_pass_over_the_factor(gpmod, n, m):
+    """Produce for M <= 64 test points (the reference's harness asks for ONE per step, tutorial/tutorial.go:178-179;
+    gp/gp.go:322-357): blocked forward substitution with the 256-block inverses in ONE persistent launch whose
+    workgroups hand v_j / w_B to each other through counters in global memory (trsm_small.hip).  Against the oracle
+    and against the tile-kernel route on the same factor -- right behind an eager Observe (the triangular inverse of
+    the gradient still occupies the GPU: uneven load, workgroups not all resident at once), after an Absorb, after a
+    Gradient, and on a restored factor; repeated calls agree bit for bit (fixed summation order)."""
+    from oracle.oracle import FastOracle
+    rng = np.random.default_rng(n * 100 + m)
+    D = 3
+    X, y = _data(rng, n, D)
+    Z = rng.uniform(-0.1, 1.1, (m, D))
+    simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
+    x = np.log([1.3, 0.6, 0.15])
+    g = gpmod.GP(D, simil, noise, X=X, Y=y)
+    g.Observe(x)
+    mu1, s1 = g.Produce(Z)            # the inverse of the eager sweep is still running
+    g.Gradient()
+    mu2, s2 = g.Produce(Z)            # idle GPU
+    np.testing.assert_array_equal(mu1, mu2)
+    np.testing.assert_array_equal(s1, s2)
+    g.set_option("produce_small_max", 0)
+    mu0, s0 = g.Produce(Z)            # the tile-kernel route on the same factor
+    g.set_option("produce_small_max", 64)
+    np.testing.assert_allclose(mu1, mu0, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(s1, s0, rtol=1e-9, atol=1e-11)
+    o = FastOracle(D, simil, noise)
+    o.set_data(X, y)
+    o.Observe(x)
+    mu_o, s_o = o.Produce(Z)
+    np.testing.assert_allclose(mu1, mu_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(s1, s_o, rtol=1e-6, atol=1e-8)
+    # a new factor by Absorb (no gradient preparation), then the same state restored into another handle
+    th = np.exp(np.log([0.9, 0.45, 0.2]))
+    g3 = gpmod.GP(D, simil, noise, ThetaSimil=th[:2], ThetaNoise=th[2:], X=X, Y=y)
+    g3.Absorb(X, y)
+    mu3, s3 = g3.Produce(Z)
+    o.Observe(np.log(th))
+    mu_o3, s_o3 = o.Produce(Z)
+    np.testing.assert_allclose(mu3, mu_o3, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(s3, s_o3, rtol=1e-6, atol=1e-8)
+    g4 = gpmod.GP(D, simil, noise, ThetaSimil=th[:2], ThetaNoise=th[2:], X=X, Y=y)
+    g4.restore(g3.L, g3.Alpha)
+    mu4, s4 = g4.Produce(Z)
+    np.testing.assert_allclose(mu4, mu3, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s4, s3, rtol=1e-9, atol=1e-12)
+    for h in (g, g3, g4):
+        h.close()
+
+
 @pytest.mark.parametrize("n,m,prec", [(700, 33, 64), (2300, 300, 64), (5000, 1100, 64), (2300, 300, 32)])
 def test_produce_through_superpanel_inverses_matches_panel_substitution(gpmod, n, m, prec):
     """Produce solves V^T = Kstar^T L^-T super-panel by super-panel through T^-1, the inverse of the factor's diagonal
@@ -411,6 +462,7 @@ def test_produce_through_superpanel_inverses_matches_panel_substitution(gpmod, n
     simil, noise = kernel.Scaled(kernel.Matern52), kernel.UniformNoise
     x = np.log([1.3, 0.6, 0.15])
     g = gpmod.GP(D, simil, noise, X=X, Y=y, precision=prec)
+    g.set_option("produce_small_max", 0)  # this test is about the tile-kernel route, whatever m (the one-pass kernel: below)
     g.Observe(x)
     mu1, s1 = g.Produce(Z)           # assembles T^-1
     mu2, s2 = g.Produce(Z)           # reuses it

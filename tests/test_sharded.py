@@ -203,6 +203,43 @@ def test_candidates_on_a_sharded_handle(grid, precision):
         np.testing.assert_allclose(res3.history, res1.history, rtol=1e-10)
 
 
+@pytest.mark.gpu
+def test_candidates_on_a_sharded_handle_keep_the_per_candidate_contract():
+    """a candidate whose parameters are unusable (exp(x) overflows: GOGP_EARG) only marks its own
+    status on a sharded handle too -- the others are evaluated, every slot is written -- exactly as on one GPU."""
+    from gogp_amd import _lib, kernel, synth
+    from gogp_amd.gp import GP
+    from gogp_amd.sharded import ShardedGP
+    import loopback
+    grid, world = (1, 2), 2
+    n, D = 700, 2
+    simil = kernel.Scaled(kernel.Normal)
+    X, y = synth.make_inputs(n, D, 79)
+    base = np.log([0.8, 0.9, 0.3])
+    xs = np.stack([base, np.array([800.0, base[1], base[2]]), base + 0.05])  # the middle one overflows
+
+    def rank_fn(r, lb):
+        sh = ShardedGP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0, grid=grid, rank=r, world=world,
+                       exchange=lb.exchange, allreduce=lb.allreduce)
+        single = [(sh.Observe(x), sh.Gradient()) for x in (xs[0], xs[2])]
+        lmls, grads, st = sh.observe_gradient_candidates(xs, strict=False)
+        sh.close()
+        return single, lmls, grads, list(st)
+
+    outs, _ = loopback.run_ranks(world, rank_fn)
+    g1 = GP(D, simil, kernel.UniformNoise, X=X, Y=y, device=0)
+    l1, gr1, st1 = g1.observe_gradient_candidates(xs, strict=False)
+    g1.close()
+    assert list(st1) == [_lib.GOGP_OK, _lib.GOGP_EARG, _lib.GOGP_OK]
+    for single, lmls, grads, st in outs:
+        assert st == [_lib.GOGP_OK, _lib.GOGP_EARG, _lib.GOGP_OK]
+        assert np.isnan(lmls[1]) and not grads[1].any()
+        for c, sc in ((0, 0), (2, 1)):
+            assert abs(lmls[c] - single[sc][0]) <= 1e-12 * abs(single[sc][0])
+            np.testing.assert_allclose(grads[c], single[sc][1], rtol=1e-12, atol=1e-12 * np.abs(single[sc][1]).max())
+            assert abs(lmls[c] - l1[c]) <= 1e-9 * abs(l1[c])
+
+
 def expected_exchange_bytes(npad, grid, nb=512):
     """Bytes sent over the transport by ONE sharded evaluation (all ranks together), from the
     layout alone -- DESIGN.md section 5: per block column P the inverse of the diagonal tile goes
