@@ -111,6 +111,24 @@ struct BlockMap {
   }
 };
 
+// ---- per-workgroup time stamps (probe build only: make stamp -> tools/exp/lib_stamp.so, -DGOGP_WGSTAMP) -----------------
+// where INSIDE a launch of the chain's tile kernel / the diagonal-block kernel the time goes
+// when it runs beside the bulk updates.  Every workgroup of those kernels writes s_memrealtime (100 MHz, one clock for the
+// whole chip) at entry / operands of the first k-step in LDS / last k-step done / stores drained, plus HW_ID and XCC_ID,
+// into a buffer the probe (tools/wg_stamps.py) hands in through these globals; one record per launch says which slice of
+// the buffer is whose.  The product library is built without the macro and contains none of this.
+#ifdef GOGP_WGSTAMP
+struct StampRec {
+  long long base, nwg, tag, stream;
+};
+constexpr int STAMP_SLOTS = 8;
+extern unsigned long long *g_stamp_buf;  // device buffer, STAMP_SLOTS x g_stamp_cap entries
+extern long long g_stamp_cap, g_stamp_used, g_stamp_nrec;
+extern StampRec g_stamp_rec[1 << 16];
+// reserve nwg workgroup slots for a launch; nullptr when the probe is not armed or the buffer is full
+unsigned long long *stamp_reserve(long long nwg, long long tag, hipStream_t s);
+#endif
+
 // ---- launchers implemented in the .hip files ------------------------------
 enum GemmMode { GEMM_RECT = 0, GEMM_LOWER = 1, GEMM_LAUUM = 2,
                 // GEMM_RECT whose tiles in strictly upper 256x256 blocks (block column > block row,

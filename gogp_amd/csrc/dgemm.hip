@@ -62,7 +62,32 @@ struct GemmArgs {
   int krag0;     // RECT / LOWER: tile rows ti >= krag0 start at k = (ti - krag0) * BT (common.h: GemmGrid); INT_MAX: none
   int kbeg0;     // GEMM_LAUUM: second of two launches (common.h: GemmGrid)
   long bstride;  // candidate batching: byte offset of A, B, C per blockIdx.z (common.h: Batch)
+#ifdef GOGP_WGSTAMP
+  unsigned long long *stamps;  // probe build: this launch's slice of the stamp buffer (common.h), or nullptr
+#endif
 };
+
+#ifdef GOGP_WGSTAMP
+unsigned long long *g_stamp_buf = nullptr;
+long long g_stamp_cap = 0, g_stamp_used = 0, g_stamp_nrec = 0;
+StampRec g_stamp_rec[1 << 16];
+unsigned long long *stamp_reserve(long long nwg, long long tag, hipStream_t s) {
+  if (!g_stamp_buf || g_stamp_used + nwg > g_stamp_cap || g_stamp_nrec >= (1 << 16)) return nullptr;
+  unsigned long long *p = g_stamp_buf + STAMP_SLOTS * g_stamp_used;
+  g_stamp_rec[g_stamp_nrec++] = {g_stamp_used, nwg, tag, (long long)(size_t)s};
+  g_stamp_used += nwg;
+  return p;
+}
+#define GOGP_STAMP_WG(k)                                                                                            \
+  do {                                                                                                              \
+    if (g.stamps && threadIdx.x == 0)                                                                               \
+      g.stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.z) * STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define GOGP_STAMP_WG(k) \
+  do {                   \
+  } while (0)
+#endif
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   // doubles; chunk = 16-B chunk index 0..7 within the 128-B row
@@ -143,6 +168,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile bases stay in SGPRs
   if (g.prio) raise_wave_priority();
+  GOGP_STAMP_WG(0);
+#ifdef GOGP_WGSTAMP
+  if (g.stamps && threadIdx.x == 0) {
+    unsigned long long *st = g.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.z) * STAMP_SLOTS;
+    st[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+    st[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+  }
+#endif
 
   // ---- tile assignment ----------------------------------------------------
   int t = blockIdx.x;
@@ -270,6 +303,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
   }
   wait_vmcnt0();  // the tile is in LDS
   __syncthreads();
+  GOGP_STAMP_WG(1);
 
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -314,6 +348,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
     cur ^= 1;
   }
 
+  GOGP_STAMP_WG(2);
   // ---- epilogue: stores only
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -322,6 +357,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void dgemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         (Cg + (long)(m * 16 + 4 * v) * g.ldc)[coff + n * 16] = alpha * acc[m][n][v];
+#ifdef GOGP_WGSTAMP
+  if (g.stamps) {
+    wait_vmcnt0();  // probe build: the stores have left
+    GOGP_STAMP_WG(3);
+  }
+#endif
 }
 
 void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, double alpha,
@@ -441,6 +482,9 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
   // launch runs a second, almost empty round at the full per-round price (528 tiles at K = 512, the last fused K^-1
   // update of an N = 4096 evaluation: 203 us); as 64 x 64 tiles it is two rounds of a quarter of the work each
   // (one N = 4096 evaluation 3.54-3.59 -> 3.48-3.50 ms; N = 16384 and 8 candidates at N = 4096 unchanged)
+#ifdef GOGP_WGSTAMP
+  g.stamps = nullptr;
+#endif
   const long total_tiles = (long)ntiles * nz;
   const bool small = (mode != GEMM_LAUUM) && (total_tiles < (grid ? grid->small_below : 384) ||
                                               (total_tiles > 512 && total_tiles <= 768));
@@ -454,12 +498,18 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
     if (g.krag0 != 0x7fffffff) g.krag0 *= 2;  // counted in 64-wide tiles (and 64-column steps of the K start)
     const int n64 = (mode == GEMM_RECT) ? (g.rule ? 8 * ((g.mt + 7) / 8) * g.nt : g.mt * g.nt)
                                         : g.mt * (g.mt + 1) / 2;
+#ifdef GOGP_WGSTAMP
+    g.stamps = stamp_reserve((long long)n64 * nz, 10000000000LL * 1 + (long long)mode * 100000000LL + (K / 16) * 100000LL + std::min(ntiles, 99999), s);
+#endif
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_RECT, 64, 4>);
     else
       GOGP_LAUNCH(dim3(n64, 1, nz), dim3(256), dgemm_nt_kernel<GEMM_LOWER, 64, 4>);
   } else if (mode == GEMM_LAUUM || total_tiles >= 3072) {
     const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles, 1, nz), block8(512);
+#ifdef GOGP_WGSTAMP
+    g.stamps = stamp_reserve((long long)grid.x * nz, 10000000000LL * 3 + (long long)mode * 100000000LL + (K / 16) * 100000LL + std::min(ntiles, 99999), s);
+#endif
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_RECT, 128, 8>);
     else if (mode == GEMM_LOWER)
@@ -468,6 +518,9 @@ void launch_dgemm_nt(hipStream_t s, GemmMode mode, int mt, int nt, int64_t K, do
       GOGP_LAUNCH(grid, block8, dgemm_nt_kernel<GEMM_LAUUM, 128, 8>);
   } else {
     const dim3 grid(g.rule ? 8 * ((mt + 7) / 8) * nt : ntiles, 1, nz), block(256);
+#ifdef GOGP_WGSTAMP
+    g.stamps = stamp_reserve((long long)grid.x * nz, 10000000000LL * 2 + (long long)mode * 100000000LL + (K / 16) * 100000LL + std::min(ntiles, 99999), s);
+#endif
     if (mode == GEMM_RECT)
       GOGP_LAUNCH(grid, block, dgemm_nt_kernel<GEMM_RECT, 128, 4>);
     else

@@ -625,14 +625,34 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
   __shared__ __attribute__((aligned(16))) double S[128 * SLD];
   __shared__ __attribute__((aligned(16))) double G[GSIZE];
   __shared__ double rinv_s[8 * 16];  // per-wave scratch of base16
+#ifdef GOGP_WGSTAMP
+  // probe build (common.h): entry / exit on the chip-wide clock; `stamps` doubles as this launch's slice of the buffer
+  unsigned long long *wgst = STAMP ? nullptr : stamps;
+  if (wgst && threadIdx.x == 0) {
+    wgst[blockIdx.z * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    wgst[blockIdx.z * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    wgst[blockIdx.z * 8 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
   diag256_body<DO_POTRF, STAMP, LDD>(S, G, rinv_s, A, ld, Lout, ldl, Dinv, row0, nvalid, info, stamps);
+#ifdef GOGP_WGSTAMP
+  if (wgst) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) wgst[blockIdx.z * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
+  unsigned long long *wgst = nullptr;
+#if defined(GOGP_WGSTAMP) && !defined(GOGP_BUILD_TESTHOOKS)
+  wgst = gogp::stamp_reserve(gogp::tl_batch.k, 90000000000LL, s);  // tag 9e10: the diagonal-block kernel
+#endif
   GOGP_KLAUNCH((diag256_kernel<true, false, 256>), dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s,
                      A, (long)ld, Lout, (long)ldl, Dinv, (long)row0, (long)nvalid, info,
-                     (unsigned long long *)nullptr, gogp::tl_batch.stride);
+                     wgst, gogp::tl_batch.stride);
 }
 
 #ifndef GOGP_BUILD_TESTHOOKS

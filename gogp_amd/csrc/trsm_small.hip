@@ -24,8 +24,9 @@
 // v[k0 + 2 fk][j] and v[k0 + 2 fk + 1][j]: the k order inside a product is free as long as both operands agree.
 // v_j lives in LDS in the same pair-interleaved layout it has in global memory ([k / 2][j][k % 2]): one
 // ds_read_b128 per MFMA pair, conflict-free (16 lanes x 16 B contiguous), staged by a straight 16-B copy.
-// The loads of L run four 64-column chunks (one 256-block) ahead of the MFMAs in a register ring and do not wait
-// for any counter (L is constant): a workgroup behind the frontier streams at the rate HBM gives it.
+// The loads of L run four 64-column chunks (one whole 256-block) ahead of the MFMAs in a register ring and do not
+// wait for any counter (L is constant): a workgroup behind the frontier streams at the rate HBM gives it, and a
+// workgroup AT the frontier has its operands in registers when v_j arrives.
 #include "common.h"
 
 namespace gogp {
@@ -101,11 +102,23 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   const int wg = blockIdx.x;
   const int B = wg / TS_WPB, sub = wg - B * TS_WPB;
   const long r0 = (long)wg * TS_RT + 16 * w;  // first row of this wave
-  const int nc = 4 * B + sub + 1;              // 64-column chunks of this workgroup: L[rows, 0:256 B], then Dinv_B[rows, 0:64 (sub+1)]
+  // 64-column chunks of this workgroup: L[rows, 0:256 B], then ALL FOUR of Dinv_B[rows, 0:256].  The chunks right of
+  // the diagonal (c > sub) are zeros and add nothing, but a ring slot that is never read again is a register hipcc
+  // hands to the reduction / publishing code behind the loop -- which then waits for the load still in flight into it
+  // (a write-after-write wait of one full HBM latency, 2.5 us, on the critical path of every block: tools/trsv_stamps.py)
+  const int nc = 4 * B + 4;
 
   // ---- operand ring: chunk q -> this lane's eight 16-B pieces --------------------------------------
   const double *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
   const double *Drow = g.Dinv + (long)B * PANEL * PANEL + (long)(sub * TS_RT + 16 * w + fr) * PANEL + 2 * fk;
+  // ---- accumulators: acc = sum_j L v_j - b  (so w = -acc); loaded BEFORE the ring's first requests (vector loads
+  // return in order: every later wait for a ring slot then covers them, see trsv_granule_kernel) ----------------
+  f64x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      acc[nt][v] = -g.KsT[(long)(g.j0 + fr + 16 * nt) * g.ldk + r0 + fk + 4 * v];
   f64x2 ar[4][8];
   auto issue = [&](int q, f64x2(&slot)[8]) {
     const double *p = (q < 4 * B) ? Lrow + (long)q * 64 : Drow + (long)(q - 4 * B) * 64;
@@ -118,14 +131,8 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   issue(0, ar[0]);
   issue(min(1, nc - 1), ar[1]);
   issue(min(2, nc - 1), ar[2]);
+  issue(min(3, nc - 1), ar[3]);
 
-  // ---- accumulators: acc = sum_j L v_j - b  (so w = -acc) -------------------------------------------
-  f64x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      acc[nt][v] = -g.KsT[(long)(g.j0 + fr + 16 * nt) * g.ldk + r0 + fk + 4 * v];
 
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.Vk, 0, (int)((long)g.nb * PANEL * MC * 8), 0x00020000);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.Wk, 0, (int)((long)g.nb * PANEL * MC * 8), 0x00020000);
@@ -212,8 +219,12 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c, ++q) {
-      issue(min(q + 3, nc - 1), ar[(c + 3) & 3]);
       chunk_mma(c, ar[c], acc);
+      // the slot just consumed takes the chunk FOUR ahead: when a block is done, the whole next block is in flight --
+      // with the request in front of the multiplication (three ahead) the last chunk of every block was only asked
+      // for once v_j had arrived, and its HBM latency sat on the substitution's critical path (tools/trsv_stamps.py:
+      // 3.7 us per block for a 0.3 us phase)
+      issue(min(q + 4, nc - 1), ar[c]);
     }
   }
   // ---- diagonal step: publish w, wait for the block's other parts, v_rows = Dinv_B[rows, :] w_B -----------
@@ -230,13 +241,9 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   f64x4 res[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) res[nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  // chunks 0 .. sub of Dinv's rows (lower triangular: the rest is zero); the ring slot of chunk 4 B + c is c & 3
+  // the four chunks of Dinv's rows (lower triangular: zeros right of the diagonal); the ring slot of chunk 4 B + c is c
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (c <= sub) {
-      if (c == 0) issue(min(4 * B + 3, nc - 1), ar[3]);  // sub = 3: the one chunk the loop above never reached
-      chunk_mma(c, ar[c], res);
-    }
+  for (int c = 0; c < 4; ++c) chunk_mma(c, ar[c], res);
   publish(g.Vk, res, 1.0);
   // partial sums of squares of this workgroup's rows, fixed order
   double sq[NT];
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   const int wg = blockIdx.x;
   const int B = wg / TS_WPB, sub = wg - B * TS_WPB;
   const long r0 = (long)wg * TS_RT + 16 * (courier ? 0 : w);
-  const int nc = 4 * B + sub + 1;
+  const int nc = 4 * B + 4;  // all four chunks of Dinv's rows (zeros right of the diagonal): see trsm_small_kernel
   const double *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
   const double *Drow = g.Dinv + (long)B * PANEL * PANEL + (long)(sub * TS_RT + 16 * (courier ? 0 : w) + fr) * PANEL + 2 * fk;
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.Vg, 0, (int)((long)g.nb * PANEL * 16), 0x00020000);
@@ -378,10 +385,15 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   // (chunk indices are clamped to the last one instead of guarded: a conditional load makes every ring register a
   // phi of "old or new" and hipcc then keeps both -- 137 VGPR spills; the repeated load of the last chunk lands in a
   // slot nobody reads any more)
+  // the right-hand side FIRST: vector loads return in order, so every later wait for a ring slot also covers it.  Loaded
+  // behind the ring's first requests, hipcc guarded its use after the loop with an s_waitcnt vmcnt(22) -- which, with the
+  // next block's 32 requests just issued, waits for ten of THEM: one full HBM latency (2.5 us) on the critical path of every
+  // block (tools/trsv_stamps.py: 3.6 us for a 0.8 us phase)
+  const double brow = g.b[r0 + fr];
   issue(0, ar[0]);
   issue(min(1, nc - 1), ar[1]);
   issue(min(2, nc - 1), ar[2]);
-  const double brow = g.b[r0 + fr];
+  issue(min(3, nc - 1), ar[3]);
   // this wave's 16 rows of one 64-column chunk c of the staged block: lane (fr, fk) adds its 16 of the 64 columns
   auto chunk_fma = [&](const double *buf, int c, const f64x2(&slot)[8], double &acc) {
 #pragma unroll
@@ -414,8 +426,8 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
     const double *buf = vs[j & 1];
 #pragma unroll
     for (int c = 0; c < 4; ++c, ++q) {
-      issue(min(q + 3, nc - 1), ar[(c + 3) & 3]);
       chunk_fma(buf, c, ar[c], acc);
+      issue(min(q + 4, nc - 1), ar[c]);  // four ahead, into the slot just consumed (see trsm_small_kernel)
     }
   }
   acc += __shfl_xor(acc, 16);
@@ -429,11 +441,7 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   {
     const double *buf = vs[B & 1];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c <= sub) {
-        if (c == 0) issue(min(4 * B + 3, nc - 1), ar[3]);
-        chunk_fma(buf, c, ar[c], res);
-      }
+    for (int c = 0; c < 4; ++c) chunk_fma(buf, c, ar[c], res);
   }
   res += __shfl_xor(res, 16);
   res += __shfl_xor(res, 32);
