@@ -841,13 +841,26 @@ def main():
                 g.profile_enable(False)
                 # algorithmic work of the solve (gp/gp.go:337-342 as ONE triangular solve): N^2 M flop
                 alg = float(N) * N * m
-                d = {"m": m, "ms_per_call": t * 1e3, "test_points_per_s": m / t,
-                     "roofline": {"bound": "mfma", "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                  "frac": alg / t / 1e12 / peak,
-                                  "algorithmic_flops_per_call": alg,
-                                  "kernel_busy_ms_per_call": busy_ms / reps,
-                                  "frac_while_kernel_runs": (alg / (busy_ms / reps * 1e-3) / 1e12 / peak) if busy_ms else None,
-                                  "launches_per_call": launches / reps, "launched_flops_per_call": flops / reps}}
+                if m <= 64 and prec == 64:
+                    # few test points: ONE persistent launch that reads the factor once (trsm_small.hip) -- bound by
+                    # the pass over the lower triangle, 8 N^2 / 2 bytes (bytes of the HBM-bound sub-steps)
+                    tri = esz * float(N) * N / 2.0
+                    d = {"m": m, "ms_per_call": t * 1e3, "test_points_per_s": m / t,
+                         "roofline": {"bound": "hbm", "achieved": tri / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": tri / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": tri,
+                                      "algorithmic_flops_per_call": alg,
+                                      "note": "one pass over the factor's lower triangle / wall time of the whole call "
+                                              "(Kstar, mean, substitution, norms, host copies); the substitution is a "
+                                              "chain of N / 256 dependent block steps inside one launch: latency-, not "
+                                              "bandwidth-bound at this N"}}
+                else:
+                    d = {"m": m, "ms_per_call": t * 1e3, "test_points_per_s": m / t,
+                         "roofline": {"bound": "mfma", "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                      "frac": alg / t / 1e12 / peak,
+                                      "algorithmic_flops_per_call": alg,
+                                      "kernel_busy_ms_per_call": busy_ms / reps,
+                                      "frac_while_kernel_runs": (alg / (busy_ms / reps * 1e-3) / 1e12 / peak) if busy_ms else None,
+                                      "launches_per_call": launches / reps, "launched_flops_per_call": flops / reps}}
                 if cross_n:
                     cb = esz * N * m
                     d["cross_kernel"] = {"algorithmic_bytes": cb, "ms": cross_ms / cross_n,
@@ -859,7 +872,18 @@ def main():
                                       "tile kernel, the test points' tile rows on up to 4 independent chains) + column "
                                       "norms, factor resident; roofline.frac = N^2 M / wall time of the whole call")
             if N >= 4096:
-                out["produce"]["m_sweep"] = [time_produce(m, reps=2) for m in (1, 64, 8192)]
+                out["produce"]["m_sweep"] = [time_produce(m, reps=3) for m in (1, 16, 64, 8192)]
+                # the reference's harness order (tutorial/tutorial.go:170-179): Observe, then Produce of ONE point right
+                # behind it -- the gradient preparation of the eager Observe still occupies the GPU
+                Z1 = wl.test_points(1)
+                g.Observe(wl.log_theta(1)); g.Produce(Z1)
+                torch.cuda.synchronize()
+                g.Observe(wl.log_theta(2))
+                tb = time.perf_counter()
+                g.Produce(Z1)
+                tb = time.perf_counter() - tb
+                torch.cuda.synchronize()
+                out["produce"]["one_point_right_behind_observe_ms"] = tb * 1e3
         out_holder["line"] = out
         out_holder["measurement_done"] = True  # on every rank: the replica value needs nothing collective any more
 

@@ -1832,21 +1832,29 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
   // T^-1 of every super-panel's diagonal block: assembled by the first Produce on a factor (a chain of tiny launches
   // on stream sk that runs ahead of the solves, which wait for their super-panel's event), kept for the later ones.
   // Not behind the factorisation: its 110 launches cost an N = 16384 Observe + Gradient 0.6 ms (measured).
-  const bool use_tinv = h->produce_tinv && h->lookahead && ensure_tinv(h) == GOGP_OK;
+  bool use_tinv = h->produce_tinv && h->lookahead;
+  if (use_tinv && ensure_tinv(h) != GOGP_OK) {  // no memory for T^-1: panel-by-panel substitution, and no stale message
+    use_tinv = false;
+    h->err.clear();
+  }
   const bool assemble = use_tinv && !(h->tinv_valid && h->tinv_sig == tinv_signature(h));
+  // Right behind an eager Observe the streams of the triangular inverse (st, s2, sk) still hold two thirds of an
+  // evaluation's flops that Produce does not depend on: everything on the main stream then
+  const bool busy = h->trtri_pending || h->kinv_pending;
+  hipStream_t sasm = busy ? s : h->sk;
   const size_t evt0 = EV_BASE + 4 * (size_t)npanel + 8 + 2 * PRODUCE_GROUPS;  // one event per super-panel behind the others
   if (assemble) {
-    order(h, EV_TINV, s, h->sk);  // behind whatever last wrote the factor (s is ordered behind the factorisation)
+    if (sasm != s) order(h, EV_TINV, s, sasm);  // behind whatever last wrote the factor (s is ordered behind the factorisation)
     for (int P0 = 0, nsub = 0; P0 < npanel; P0 += nsub) {
       nsub = std::min(pw, npanel - P0);
-      assemble_tinv<T>(h, h->sk, P0, nsub);
-      (void)gogp::rec_event_record(ev(h, evt0 + (size_t)P0), h->sk);
+      assemble_tinv<T>(h, sasm, P0, nsub);
+      (void)gogp::rec_event_record(ev(h, evt0 + (size_t)P0), sasm);
     }
     h->tinv_valid = true;
     h->tinv_sig = tinv_signature(h);
   }
   hipStream_t gs[PRODUCE_GROUPS] = {s, h->s2, h->st, h->sp};
-  int ngroups = h->lookahead ? std::min(h->produce_groups, std::min(mt, PRODUCE_GROUPS)) : 1;
+  int ngroups = (h->lookahead && !busy) ? std::min(h->produce_groups, std::min(mt, PRODUCE_GROUPS)) : 1;
   if (ngroups < 1) ngroups = 1;
   const size_t ev0 = EV_BASE + 4 * (size_t)npanel + 8;  // behind the factorisation's own event slots
   for (int g = 1; g < ngroups; ++g) order(h, ev0 + g, s, gs[g]);  // Kstar^T (and whatever s held) first
@@ -1862,7 +1870,7 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
       gtri.ktri = h->ktri;
       gtri.small_below = gup.small_below = h->produce_small_below;
       if (use_tinv) {
-        if (assemble) (void)gogp::rec_stream_wait(sg, ev(h, evt0 + (size_t)P0));
+        if (assemble && sg != sasm) (void)gogp::rec_stream_wait(sg, ev(h, evt0 + (size_t)P0));
         // the whole super-panel at once: V[:, C0:CE] = R[:, C0:CE] T^-T with the assembled inverse of the factor's
         // diagonal block -- the same flops as the panel-by-panel substitution (T^-1 is lower triangular: ktri), 2
         // dependent launches per super-panel instead of 2 per 256 columns
@@ -1914,16 +1922,18 @@ static int produce_small(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad,
   htmo[0] = htmo[1] = 0;
   const int m1 = (int)std::min<int64_t>(m, 32);
   const size_t ev0 = EV_BASE + 4 * (size_t)(npad / PANEL) + 8;  // Produce's event slots behind the factorisation's own
+  // (right behind an eager Observe s2 carries the triangular inverse: both launches on the main stream then)
+  hipStream_t s2nd = (h->trtri_pending || h->kinv_pending) ? s : h->s2;
   if (m > 32) {
     // the second 32 columns on a second stream, beside the first (both launches read the same factor at the same
     // time: what one pulls into the Infinity Cache the other finds there)
-    order(h, ev0 + 1, s, h->s2);
-    launch_trsm_small(h->s2, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 32, (int)m - 32, (char *)h->small_ws + one, dq, &tmo2);
-    HIPCHK(h, hipMemcpyAsync(htmo + 1, tmo2, sizeof(unsigned), hipMemcpyDeviceToHost, h->s2));
+    if (s2nd != s) order(h, ev0 + 1, s, s2nd);
+    launch_trsm_small(s2nd, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 32, (int)m - 32, (char *)h->small_ws + one, dq, &tmo2);
+    HIPCHK(h, hipMemcpyAsync(htmo + 1, tmo2, sizeof(unsigned), hipMemcpyDeviceToHost, s2nd));
   }
   launch_trsm_small(s, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 0, m1, h->small_ws, dq, &tmo);
   HIPCHK(h, hipMemcpyAsync(htmo, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  if (m > 32) order(h, ev0 + PRODUCE_GROUPS + 1, h->s2, s);
+  if (m > 32 && s2nd != s) order(h, ev0 + PRODUCE_GROUPS + 1, s2nd, s);
   return GOGP_OK;
 }
 

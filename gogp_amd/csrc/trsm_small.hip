@@ -329,6 +329,7 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   // the courier's sweep: lane l re-reads the granule pairs l, l + 64, l + 128, l + 192 of block blk until all 256 carry
   // the tag, then writes the doubles to buf
   auto sweep = [&](bool from_w, int blk, double *buf, unsigned code) {
+    const int slack = from_w ? 0 : min(B - 1 - blk, 16);  // block steps until this workgroup is the frontier
     const unsigned off = ((unsigned)blk * PANEL + (unsigned)lane) * 16u;
     u32x4 x[4];
     for (unsigned spins = 0;; ++spins) {
@@ -349,6 +350,11 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
         }
         break;
       }
+      // Every workgroup behind block blk needs these 4 KB next, and they all finished the previous block at about the
+      // same time: 250 couriers re-reading the SAME 64 lines back to back are a hot spot on one memory channel -- in
+      // front of the granule stores they are waiting for.  Only the block that is next in line (slack 0) polls back to
+      // back; the others can afford to see v_j late by their distance from the frontier and sleep in proportion.
+      for (int z = 0; z < slack; ++z) __builtin_amdgcn_s_sleep(8);
       if (spins >= 64u) __builtin_amdgcn_s_sleep(2);
     }
 #pragma unroll
@@ -395,13 +401,19 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   issue(min(2, nc - 1), ar[2]);
   issue(min(3, nc - 1), ar[3]);
   // this wave's 16 rows of one 64-column chunk c of the staged block: lane (fr, fk) adds its 16 of the 64 columns
+  // (the chunk's eight LDS reads first, then two independent chains of eight multiply-adds: one chain of 64 dependent
+  // fp64 operations per block, each behind its own LDS wait, was most of the 3.3 us this phase took)
   auto chunk_fma = [&](const double *buf, int c, const f64x2(&slot)[8], double &acc) {
+    f64x2 vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vv[i] = *reinterpret_cast<const f64x2 *>(buf + c * 64 + i * 8 + 2 * fk);
+    double e = 0.0, o = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const f64x2 vv = *reinterpret_cast<const f64x2 *>(buf + c * 64 + i * 8 + 2 * fk);
-      acc = fma(slot[i].x, vv.x, acc);
-      acc = fma(slot[i].y, vv.y, acc);
+      e = fma(slot[i].x, vv[i].x, e);
+      o = fma(slot[i].y, vv[i].y, o);
     }
+    acc += e + o;
   };
   // one write-through 16-byte store per row: {tag, low, tag, high}
   auto publish = [&](bool to_w, double val) {
