@@ -772,6 +772,74 @@ static void mixed_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
   }
 }
 
+// ---- option "chain_split" (fp64): the diagonal block in two halves, the products between them on the tile kernel -----
+// Measured (tools/wg_stamps.py, N = 4096): the 256-block kernel takes 130 us, sixteen of them are 2.09 of the 3.26 ms the
+// Cholesky chain of one evaluation lasts; 40 % of it are four 128^3 products on one compute unit.  Here the chain per
+// 256-panel is diag128 (half 0) -> L[c1:, c0:c1] = A[c1:, c0:c1] X00^T -> A[c1:, c1:c2] -= L[c1:, c0:c1] L[c1:c2, c0:c1]^T
+// -> diag128 (half 1) -> L[c2:, c1:c2] = A[c2:, c1:c2] X11^T: five short launches instead of two, each GEMM with K = 128.
+// -1 (default): on where the evaluation is latency-bound (npad <= 8192); beside the bulk updates of a large N every
+// chain launch costs its dispatch (wg_stamps: 80 of 144 us for a K = 256 panel solve at N = 16384), so more launches lose.
+// Measured (tools/split_probe.py): Observe + Gradient N = 1024 0.89 -> 0.84 ms, 2048 1.65 -> 1.46, 4096 3.50 -> 3.25, 8192
+// 12.2 -> 12.2, 16384 72.2 -> 73.0; the Cholesky alone (eager = 0) 4096 3.28 -> 2.72, 8192 8.2 -> 7.3, 16384 33.3 -> 31.9:
+// so also on at any size when no fp64 inverse runs beside the factorisation (Absorb, eager = 0, the mixed gradient).
+static inline bool chain_split_of(const gogp_handle *h, bool eager) {
+  if (h->dist || h->prec != 64) return false;
+  if (h->chain_split >= 0) return h->chain_split != 0;
+  return h->npad <= 8192 || !eager || (h->grad_prec == 32 && !h->batch_mode);
+}
+static void split_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, double *Dp, int64_t ld, int64_t c0,
+                        int64_t npad, GemmProfile *pf) {
+  const int64_t c1 = c0 + TILE, c2 = c0 + PANEL;
+  const int mt1 = (int)((npad - c1) / TILE), mt2 = (int)((npad - c2) / TILE);
+  GemmGrid gtri, gch;
+  gtri.ktri = h->ktri;
+  gtri.prio = gch.prio = chain_prio_of(h);
+  launch_diag128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, 0, c0, h->n, h->info);
+  // L10 and the first half of the panel below the block: rows c1.. of columns c0 .. c1
+  launch_gemm_nt(sp, GEMM_RECT, mt1, 1, TILE, 1.0, A + c1 * ld + c0, ld, Dp, PANEL, 0.0, L + c1 * ld + c0, ld, pf, &gtri);
+  // the second half of the panel's columns, from the diagonal block's A11 down
+  launch_gemm_nt(sp, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0, ld, 1.0, A + c1 * ld + c1, ld,
+                 pf, &gch);
+  launch_diag128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, 1, c0, h->n, h->info);
+  if (mt2 > 0)
+    launch_gemm_nt(sp, GEMM_RECT, mt2, 1, TILE, 1.0, A + c2 * ld + c1, ld, Dp + (size_t)TILE * PANEL + TILE, PANEL, 0.0,
+                   L + c2 * ld + c1, ld, pf, &gtri);
+}
+static void split_panel(gogp_handle *, hipStream_t, float *, float *, float *, int64_t, int64_t, int64_t, GemmProfile *) {}
+// X10 = -X11 (L10 X00) for the nsub diagonal blocks of a super-panel: two batched 128^3 products (solve.hip:
+// blockmm_kernel); M = L10 X00 goes through the block's A10 position in bufA, which is dead once split_panel has read it
+static void x10_blocks(gogp_handle *h, hipStream_t s, double *A, const double *L, double *Dinv, int64_t ld, int P0, int nsub) {
+  (void)h;
+  for (int b0 = 0; b0 < nsub; b0 += 6) {
+    const int nb = std::min(6, nsub - b0);
+    const double *A1[6], *B1[6], *A2[6], *B2[6];
+    double *C1[6], *C2[6];
+    int64_t lda1[6], ldb1[6], ldc1[6], lda2[6], ldb2[6], ldc2[6];
+    int K[6];
+    for (int b = 0; b < nb; ++b) {
+      const int p = P0 + b0 + b;
+      const int64_t c0 = (int64_t)p * PANEL, c1 = c0 + TILE;
+      double *Dp = Dinv + (size_t)p * PANEL * PANEL;
+      A1[b] = L + c1 * ld + c0;
+      lda1[b] = ld;
+      B1[b] = Dp;
+      ldb1[b] = PANEL;
+      C1[b] = A + c1 * ld + c0;
+      ldc1[b] = ld;
+      A2[b] = Dp + (size_t)TILE * PANEL + TILE;
+      lda2[b] = PANEL;
+      B2[b] = C1[b];
+      ldb2[b] = ld;
+      C2[b] = Dp + (size_t)TILE * PANEL;
+      ldc2[b] = PANEL;
+      K[b] = TILE;
+    }
+    launch_blockmm(s, nb, A1, lda1, B1, ldb1, C1, ldc1, K, 1.0, TILE);
+    launch_blockmm(s, nb, A2, lda2, B2, ldb2, C2, ldc2, K, -1.0, TILE);
+  }
+}
+static void x10_blocks(gogp_handle *, hipStream_t, float *, const float *, float *, int64_t, int, int) {}
+
 template <class T>
 static int factorize_t(gogp_handle *h, bool eager) {
   const int64_t npad = h->npad, ld = npad;
@@ -847,6 +915,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
+  const bool split = std::is_same<T, double>::value && chain_split_of(h, eager);
   if (!h->batch_mode) h->tinv_valid = false;  // Produce assembles T^-1 of the new factor on its first call
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
@@ -869,11 +938,19 @@ static int factorize_t(gogp_handle *h, bool eager) {
       const int p = P0 + q;
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
       T *Dp = Dinv + (size_t)p * PANEL * PANEL;
+      const int mt2 = (int)((npad - c2) / TILE);
+      if (split) {
+        // option "chain_split": the two 128 x 128 halves of the diagonal block are factored and inverted on their own
+        // (diag256.hip: diag128_kernel) and the three products between them -- which the 256-block kernel does on ONE
+        // compute unit -- go to the tile kernel for ALL rows of the panel at once: they are the panel solve and the
+        // update of the panel's second half.  X10 (the inverse's off-diagonal block) leaves the chain: x10_blocks below.
+        split_panel(h, sp, A, L, Dp, ld, c0, npad, pf);
+      } else {
       // 256x256 diagonal block: factor + dense inverse, one workgroup
       diag_block(h, sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, Dp, c0);
-      const int mt2 = (int)((npad - c2) / TILE);
+      }
       // L[c2:, c0:c2] = A[c2:, c0:c2] * inv(L_pp)^T   (one K=256 GEMM)
-      if (mt2 > 0) {
+      if (mt2 > 0 && !split) {
         GemmGrid gtri;  // Dp is lower triangular: the first tile column only needs k < 128
         gtri.ktri = h->ktri;
         gtri.prio = chain_prio_of(h);
@@ -900,6 +977,15 @@ static int factorize_t(gogp_handle *h, bool eager) {
     order(h, EV_BASE + 4 * P0, sp, s);  // panels P0 .. P0+nsub-1 of L are final
     if (sz != sp) (void)gogp::rec_stream_wait(sz, ev(h, EV_BASE + 4 * P0));
 
+    if (split) {
+      // X10 = -X11 (L10 X00) of the super-panel's diagonal blocks, off the chain: the substitution steps right below and
+      // the triangular inverse (st) are its first readers
+      x10_blocks(h, sz, A, L, Dinv, ld, P0, nsub);
+      if (eager) {
+        (void)gogp::rec_event_record(ev(h, EV_BASE + 5 * (size_t)npanel + 32 + (size_t)P0), sz);
+        (void)gogp::rec_stream_wait(st, ev(h, EV_BASE + 5 * (size_t)npanel + 32 + (size_t)P0));
+      }
+    }
     for (int q = 0; q < nsub; ++q)
       launch_trsv_fwd_step(sz, L, ld, Dinv, P0 + q, npanel, h->w, h->z);
     // ---- trailing update, rank nsub*256 ------------------------------------------------------
@@ -2329,6 +2415,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "chain_prio") == 0) {  // -1: by size, 0: off, 1: the chains' skinny launches, 2: all their launches
     if (value < -1 || value > 2) return fail(h, GOGP_EARG, "chain_prio must be -1..2");
     h->chain_prio = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "chain_split") == 0) {  // -1: by size, 0: 256-block kernel, 1: two 128-halves + products on the tile kernel
+    if (value < -1 || value > 1) return fail(h, GOGP_EARG, "chain_split must be -1..1");
+    h->chain_split = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "ktri") == 0) {

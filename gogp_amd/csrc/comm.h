@@ -50,5 +50,11 @@ Transport *make_rccl_transport(int rank, int nranks, const void *unique_id128, s
 Transport *make_callback_transport(int rank, int nranks, gogp_exchange_fn ex, gogp_allreduce_fn ar,
                                    void *user);
 int rccl_unique_id(void *id128);
+// Measurement only (libgogp_testhooks.so: gogp_test_dist_init_replay): rank `rank` of an nranks-grid ALONE on a GPU.
+// Nothing is sent; a receive zero-fills its buffer on the communication stream (the bytes a peer would have written),
+// an all-reduce leaves its argument as it is.  Every launch of the rank's own share of the sweep runs with its real
+// shape -- the tile kernel's time does not depend on the values -- so the evaluation's wall time is that rank's COMPUTE
+// time; the numbers it returns mean nothing.
+Transport *make_replay_transport(int rank, int nranks);
 
 }  // namespace gogp

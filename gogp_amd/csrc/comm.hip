@@ -194,4 +194,35 @@ Transport *make_callback_transport(int rank, int nranks, gogp_exchange_fn ex, go
   return t;
 }
 
+// ---- replay: one rank of a grid alone on a GPU (measurement only, comm.h) -------------------------------------------
+class ReplayTransport : public Transport {
+ public:
+  int rank = 0, nranks = 1;
+  int64_t recv_bytes = 0, send_bytes = 0;
+  const char *name() const override { return "replay (one rank of the grid alone: receives zero-fill, nothing is sent)"; }
+  bool async() const override { return true; }
+  int comm_ranks() const override { return nranks; }
+  int group(hipStream_t sc, const std::vector<XferOp> &ops, std::string *err) override {
+    for (const XferOp &o : ops) {
+      if (o.send) {
+        send_bytes += o.count * 8;
+        continue;
+      }
+      recv_bytes += o.count * 8;
+      if (hipMemsetAsync(o.ptr, 0, (size_t)o.count * sizeof(double), sc) != hipSuccess) {
+        if (err) *err = "replay transport: hipMemsetAsync failed";
+        return GOGP_EHIP;
+      }
+    }
+    return GOGP_OK;
+  }
+  int allreduce(hipStream_t, double *, int64_t, std::string *) override { return GOGP_OK; }
+};
+Transport *make_replay_transport(int rank, int nranks) {
+  ReplayTransport *t = new ReplayTransport();
+  t->rank = rank;
+  t->nranks = nranks;
+  return t;
+}
+
 }  // namespace gogp

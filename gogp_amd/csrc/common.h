@@ -228,6 +228,10 @@ void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, in
 // the same with Dinv written into a 256x256 sub-block of a matrix of leading dimension 512
 void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                           double *Dinv, int64_t row0, int64_t nvalid, long long *info);
+// one 128 x 128 half (0 / 1) of the 256-block: factor + its inverse into the block's own quarter of Lout / Dinv (option
+// "chain_split": the tile kernel does the products between the halves, api.hip)
+void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv, int half,
+                    int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
 void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv);  // Dinv: ld 512
 void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd, int rows,
@@ -287,7 +291,7 @@ void launch_ydiag(hipStream_t s, const double *Dinv, double *Ydiag, int64_t ld);
 void launch_tinv_init(hipStream_t s, const double *Dinv, double *X, double *XT, int nsub, int64_t tld);
 void launch_tinv_init(hipStream_t s, const float *Dinv, float *X, float *XT, int nsub, int64_t tld);
 void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
-                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha);
+                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha, int side = 256);
 void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
                     const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha);
 // fp32 path: out[0] = sum_{i<n} alpha_i^2 - |Y|_F^2 (= tr(alpha alpha^T - K^-1)) in fp64 from Y = L^-T; part: n doubles

@@ -644,6 +644,58 @@ __global__ __launch_bounds__(NT) void diag256_kernel(const double *__restrict__ 
 #endif
 }
 
+// ---- one 128 x 128 half of a diagonal block on its own (option "chain_split", api.hip) ---------------------------------
+// The 256-block kernel above spends 40 % of its 128 us on four 128^3 products that ONE compute unit has to do alone --
+// L10 = A10 X00^T and the Schur complement between the two halves, X10 = -X11 L10 X00 at the end.  Where an evaluation
+// is a chain of dependent launches (N <= 8192: sixteen diagonal blocks are 60 % of one N = 4096 evaluation) the sweep
+// can instead factor and invert the two 128 x 128 halves with this kernel and give the products to the tile kernel,
+// which does them for ALL rows of the panel at once (they ARE the panel solve and the update of the panel's second
+// half); X10 is then only needed by the substitutions and the triangular inverse and is formed off the chain.
+// half 0: A00 -> L00, X00 (and the zero blocks right of them); half 1: the updated A11 -> L11, X11.
+__global__ __launch_bounds__(NT) void diag128_kernel(const double *__restrict__ A, long ld, double *__restrict__ Lout,
+                                                      long ldl, double *__restrict__ Dinv, int half, long row0,
+                                                      long nvalid, long long *info, long bstride) {
+  A = gogp::cand(A, bstride);  // candidate batching (common.h: Batch)
+  Lout = gogp::cand(Lout, bstride);
+  Dinv = gogp::cand(Dinv, bstride);
+  if (info) info = gogp::cand(info, bstride);
+  __shared__ __attribute__((aligned(16))) double S[128 * SLD];
+  __shared__ __attribute__((aligned(16))) double G[GSIZE];
+  __shared__ double rinv_s[8 * 16];
+  const int tid = threadIdx.x;
+  const long off = half * 128;
+#pragma unroll 2
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
+    const int i = idx >> 6, cc = (idx & 63) * 2;
+    const f64x2 v = *reinterpret_cast<const f64x2 *>(A + (off + i) * ld + off + cc);
+    *reinterpret_cast<f64x2 *>(S + i * SLD + cc) = (f64x2){(cc <= i) ? v.x : 0.0, (cc + 1 <= i) ? v.y : 0.0};
+  }
+  __syncthreads();
+  potrf128_lds(S, G, rinv_s, tid, row0 + off, nvalid, info);
+#pragma unroll 2
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
+    const int i = idx >> 6, cc = (idx & 63) * 2;
+    *reinterpret_cast<f64x2 *>(Lout + (off + i) * ldl + off + cc) = *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+    if (half == 0) *reinterpret_cast<f64x2 *>(Lout + i * ldl + 128 + cc) = (f64x2){0.0, 0.0};
+  }
+  __syncthreads();
+  invert128_lds(S, G, tid);
+#pragma unroll 2
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
+    const int i = idx >> 6, cc = (idx & 63) * 2;
+    *reinterpret_cast<f64x2 *>(Dinv + (off + i) * 256 + off + cc) = *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+    if (half == 0) *reinterpret_cast<f64x2 *>(Dinv + i * 256 + 128 + cc) = (f64x2){0.0, 0.0};
+  }
+}
+
+#ifndef GOGP_BUILD_TESTHOOKS
+void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv, int half,
+                    int64_t row0, int64_t nvalid, long long *info) {
+  GOGP_KLAUNCH(diag128_kernel, dim3(1, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s, A, (long)ld, Lout, (long)ldl, Dinv,
+               half, (long)row0, (long)nvalid, info, gogp::tl_batch.stride);
+}
+#endif
+
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info) {
   unsigned long long *wgst = nullptr;

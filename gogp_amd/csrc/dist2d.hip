@@ -221,6 +221,15 @@ extern "C" int gogp_dist_init_rccl(gogp_handle *h, int rank, int nranks, int pro
   return dist_init_common(h, rank, nranks, prow, pcol, tr);
 }
 
+// measurement only: rank `rank` of a prow x pcol grid alone on this GPU behind the replay transport (comm.h).  A C++
+// symbol for libgogp_testhooks.so (gogp_test_dist_init_replay), not part of the C ABI.
+namespace gogp {
+int dist_init_replay(gogp_handle *h, int rank, int nranks, int prow, int pcol) {
+  if (!h) return GOGP_EARG;
+  return dist_init_common(h, rank, nranks, prow, pcol, make_replay_transport(rank, nranks));
+}
+}  // namespace gogp
+
 extern "C" int gogp_dist_init_callbacks(gogp_handle *h, int rank, int nranks, int prow, int pcol,
                                         gogp_exchange_fn exchange, gogp_allreduce_fn allreduce,
                                         void *user) {

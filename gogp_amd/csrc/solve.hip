@@ -487,6 +487,7 @@ struct BlockMM {
   int K[BLOCKMM_MAX];
   double alpha;
   long bstride;
+  int tshift;  // 64 x 64 tiles per side of a product: 1 << tshift (256 x 256: 2; 128 x 128: 1)
 };
 typedef double bmm_f64x4 __attribute__((ext_vector_type(4)));
 template <class T>
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void blockmm_kernel(BlockMM<T> g) {
   const long lda = g.lda[b], ldb = g.ldb[b], ldc = g.ldc[b];
   const int K = g.K[b];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tr = blockIdx.x >> 2, tc = blockIdx.x & 3;  // 64 x 64 tile of the 256 x 256 product
+  const int tr = blockIdx.x >> g.tshift, tc = blockIdx.x & ((1 << g.tshift) - 1);  // 64 x 64 tile of the product
   A += (long)tr * 64 * lda;
   B += tc * 64;
   C += (long)tr * 64 * ldc + tc * 64;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void blockmm_kernel(BlockMM<T> g) {
 template <class T>
 static void launch_blockmm_t(hipStream_t s, int nprod, const T *const *A, const int64_t *lda, const T *const *B,
                              const int64_t *ldb, T *const *C, const int64_t *ldc, const int *K, double alpha,
-                             unsigned nz, long bstride) {
+                             unsigned nz, long bstride, int side = 256) {
   if (nprod <= 0) return;
   BlockMM<T> g;
   for (int b = 0; b < nprod; ++b) {
@@ -560,11 +561,12 @@ static void launch_blockmm_t(hipStream_t s, int nprod, const T *const *A, const 
   }
   g.alpha = alpha;
   g.bstride = bstride;
-  GOGP_KLAUNCH(blockmm_kernel<T>, dim3(16, (unsigned)nprod, nz), dim3(256), 0, s, g);
+  g.tshift = side == 128 ? 1 : 2;
+  GOGP_KLAUNCH(blockmm_kernel<T>, dim3(1u << (2 * g.tshift), (unsigned)nprod, nz), dim3(256), 0, s, g);
 }
 void launch_blockmm(hipStream_t s, int nprod, const double *const *A, const int64_t *lda, const double *const *B,
-                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha) {
-  launch_blockmm_t<double>(s, nprod, A, lda, B, ldb, C, ldc, K, alpha, (unsigned)tl_batch.k, tl_batch.stride);
+                    const int64_t *ldb, double *const *C, const int64_t *ldc, const int *K, double alpha, int side) {
+  launch_blockmm_t<double>(s, nprod, A, lda, B, ldb, C, ldc, K, alpha, (unsigned)tl_batch.k, tl_batch.stride, side);
 }
 void launch_blockmm(hipStream_t s, int nprod, const float *const *A, const int64_t *lda, const float *const *B,
                     const int64_t *ldb, float *const *C, const int64_t *ldc, const int *K, double alpha) {

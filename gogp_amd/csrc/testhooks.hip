@@ -7,6 +7,14 @@
 #include "common.h"
 #include "../../include/gogp_testhooks.h"
 
+struct gogp_handle;
+namespace gogp {
+int dist_init_replay(gogp_handle *h, int rank, int nranks, int prow, int pcol);  // dist2d.hip
+}
+extern "C" int gogp_test_dist_init_replay(void *h, int rank, int nranks, int prow, int pcol) {
+  return gogp::dist_init_replay(static_cast<gogp_handle *>(h), rank, nranks, prow, pcol);
+}
+
 namespace gogp_th {
 void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl,
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);

@@ -41,7 +41,7 @@ class ShardedGP(GP):
         process (one thread each), which is how the tests rehearse 2x4 and 4x4 grids on one GPU."""
         import torch
         import torch.distributed as dist
-        have_pg = dist.is_available() and dist.is_initialized() and exchange is None
+        have_pg = dist.is_available() and dist.is_initialized() and exchange is None and transport != "replay"
         backend = dist.get_backend(group) if have_pg else ("in-process" if exchange else "none")
         nworld = dist.get_world_size(group) if have_pg else (world or 1)
         if transport is None:
@@ -104,8 +104,15 @@ class ShardedGP(GP):
                 self._h, self._rank, self._world, self.grid[0], self.grid[1],
                 ctypes.cast(self._exchange_cb, ctypes.c_void_p),
                 ctypes.cast(self._allreduce_cb, ctypes.c_void_p), None))
+        elif transport == "replay":
+            # measurement only (tools/sharded_replay.py): this object is rank `rank` of the grid ALONE on its GPU; the
+            # hook library installs a transport that sends nothing and zero-fills what would have been received
+            hooks = ctypes.CDLL(_lib.HOOKS_PATH)
+            hooks.gogp_test_dist_init_replay.restype = ctypes.c_int
+            hooks.gogp_test_dist_init_replay.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+            self._check(hooks.gogp_test_dist_init_replay(self._h, self._rank, self._world, self.grid[0], self.grid[1]))
         else:
-            raise ValueError("transport must be 'rccl' or 'callbacks'")
+            raise ValueError("transport must be 'rccl', 'callbacks' or 'replay'")
 
     # ---- callbacks (host buffers; never let an exception cross the C boundary) ----------------
     def _global(self, r):

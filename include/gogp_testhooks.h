@@ -45,6 +45,12 @@ int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
 int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
                       unsigned long long *stamps, double *elapsed_us);
 
+/* Per-rank replay of a sharded evaluation (tools/sharded_replay.py): makes handle `h` (a
+ * gogp_handle of the product library) rank `rank` of a prow x pcol grid ALONE on its GPU -- nothing is sent, a receive
+ * zero-fills its buffer, an all-reduce is the identity.  Every launch of that rank's share of the sweep runs with its
+ * real shape, so the wall time of Observe + Gradient is the rank's compute time; the values returned mean nothing. */
+int gogp_test_dist_init_replay(void *h, int rank, int nranks, int prow, int pcol);
+
 #ifdef __cplusplus
 }
 #endif

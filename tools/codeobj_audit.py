@@ -32,7 +32,8 @@ SGPR_SPILL_ALLOW = {
     # as LDS broadcasts instead of 240 v_readlane results that hipcc hoisted and spilled); what is left are the
     # sixteen lane == j masks of panel16 (hoisted out of the column-block loop) and kernel arguments
     r"diag256_kernel<true, false, \d+>": 160,
-    r"diag256_wait_kernel<\d+>": 160,  # the same body behind the input-flag poll (option diag_early)
+    # one 128-half of the block on its own (option chain_split): the same potrf128_lds / inv16 code, the same masks
+    r"diag128_kernel": 110,
     # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor (round 4: 248 -> 6)
     r"diag256_kernel<false, false, \d+>": 48,
     # multi-term / periodic kernels keep the per-pair loop: kind, scale, period and length tables of up to
