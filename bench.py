@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="gogp_set_option on the benchmarked handle (A/B runs), e.g. superpanel=3")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="--gpus 1: also time the SHARDED code path (dist2d.hip) on a 1x1 grid over the RCCL transport "
+                         "and report it beside the fused sweep as `sharded_1x1` (default for configs 4 and 5)")
     ap.add_argument("--sharded-timeout", type=int, default=300)
     ap.add_argument("--preflight-timeout", type=int, default=30,
                     help="seconds per pre-flight phase of an N > 1 run before the watchdog ends it")
@@ -818,6 +821,33 @@ def main():
                         "(gogp_set_data drains the streams and copies synchronously), one candidate at a time"}
             g.set_data_device(dX.data_ptr(), dy.data_ptr(), N)
             g.Observe(wl.log_theta(0))  # new data invalidate the factorisation: Produce below needs one
+        if world == 1 and g is not None and (args.sharded or (wl.sharded and not args.no_sharded)) and cps == 1:
+            # the code path configs[3] / configs[4] run on 8 GPUs, on the one GPU there is: a 1x1 grid of the 2-D
+            # block-cyclic sweep over the RCCL transport (one rank: communicator, all-reduces, every launch and filter of
+            # dist2d.hip) beside the fused single-GPU sweep -- its per-rank efficiency
+            try:
+                from gogp_amd.sharded import ShardedGP
+                s11 = ShardedGP(D, simil, noise, X=X, Y=y, device=local_rank, precision=prec, grid=(1, 1))
+                s11.Observe(wl.log_theta(0)); s11.Gradient()
+                torch.cuda.synchronize()
+                r11 = 2 if N > 40000 else 3
+                t11 = time.perf_counter()
+                for r in range(r11):
+                    l11 = s11.Observe(wl.log_theta(1 + r)); g11 = s11.Gradient()
+                torch.cuda.synchronize()
+                t11 = (time.perf_counter() - t11) / r11
+                lf = g.Observe(wl.log_theta(r11)); gf = g.Gradient()
+                out["sharded_1x1"] = {
+                    "ms_per_eval": t11 * 1e3, "evals_per_s": 1.0 / t11, "frac_wall": float(N) ** 3 / t11 / 1e12 / peak,
+                    "over_fused_sweep": t11 / (dt / steps), "transport": s11.transport_text(),
+                    "lml_rel_diff_vs_fused": abs(l11 - lf) / abs(lf),
+                    "grad_rel_diff_vs_fused": float(np.abs(g11 - gf).max() / max(1e-300, np.abs(gf).max())),
+                    "note": "ONE rank of the sharded sweep (nb = 512 block columns, rank-512 updates of K^-1 behind the "
+                            "inverse, own tiles only) against `ms_per_step` of the fused sweep; per-rank compute times of a "
+                            "2x4 grid: tools/sharded_replay.py, profiles/r05_sharded_replay*.json"}
+                s11.close()
+            except Exception as e:  # noqa: BLE001
+                out["sharded_1x1"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_produce and g is not None:
             # secondary metric: Produce throughput at the same N, M = 1024 fresh
             # test points per call, host Z in / host mu, sigma out -- outside the timed region
