@@ -330,7 +330,9 @@ func (gp *GP) ObserveGradientCandidates(xs [][]float64) (lml []float64, grad [][
 // counterpart).  "gradient_precision" = 32 keeps Observe's LML, Alpha and Produce in fp64 and runs
 // what only Gradient needs (the triangular inverse and K^-1) on the fp32 matrix cores: the gradient
 // stays within ~1e-8 of the fp64 one (the reference checks its own to 1e-4, gp/gp_test.go:170,248)
-// at 19 instead of 14 evaluations per second at N = 16384.
+// at 19 instead of 14 evaluations per second at N = 16384.  Only for kernels of ONE term with an output
+// scale: for a sum of terms the library refuses the option (an error) rather than return scale components
+// read off the float K^-1 (1.9e-4 measured).
 func (gp *GP) SetOption(name string, value int64) error {
 	cn := C.CString(name)
 	defer C.free(unsafe.Pointer(cn))

@@ -1681,7 +1681,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
     // the sweep's real cross-stream dependencies as edges, no stream captured), up to npad = 8192 -- bit-identical to
     // the streams, but this runtime executes parallel branches no faster than their serialisation (N = 4096: 6.1 ms
     // against 3.7 ms on the streams), so it is not the default.  0: streams.
-    const bool dag = h->use_graph == 2;
+    const bool dag = h->use_graph >= 2;  // 3: the same recorder as ONE chain in enqueue order (diagnostics)
     const bool graph = h->use_graph && h->prec == 64 && !h->prof.on && !h->graph_failed &&
                        h->npad <= (dag ? GRAPH_EXPLICIT_MAX_NPAD : GRAPH_MAX_NPAD);
     auto &key = h->cand_graph_key;
@@ -1713,6 +1713,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
         drop_cand_graph(h);
         HIPCHK(h, graph_stream(h));
         gogp::GraphRec rec;
+        rec.chain = h->use_graph == 3;
         HIPCHK(h, hipGraphCreate(&rec.graph, 0));
         gogp::tl_rec = &rec;
         r = enqueue();
@@ -2345,6 +2346,12 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   }
   if (strcmp(name, "gradient_precision") == 0) {  // 64 (default) | 32: Y = L^-T and K^-1 on the fp32 tile kernel (fp64 handle)
     if (value != 32 && value != 64) return fail(h, GOGP_EARG, "gradient_precision must be 32 or 64");
+    // Offered for ONE term with an output scale only: there the components of the gradient that cancel (trace, output
+    // scale) come from closed forms and the gradient stays ~1e-8 from the fp64 one.  A SUM of terms has no closed form
+    // per term: its scale components would be sums over the float K^-1 (measured 1.9e-4 on the hyperpriors kernel,
+    // above the 1e-4 the reference checks its own gradient to, gp_test.go:170,248) -- refused rather than shipped.
+    if (value == 32 && (h->desc.nterms != 1 || h->desc.terms[0].scale_idx < 0))
+      return fail(h, GOGP_EARG, "gradient_precision = 32 is offered for one-term kernels with an output scale only");
     HIPCHK(h, hipSetDevice(h->device));
     for (hipStream_t q : work_streams(h)) HIPCHK(h, hipStreamSynchronize(q));
     h->grad_prec = (int)value;
@@ -2435,7 +2442,7 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     return GOGP_OK;
   }
   if (strcmp(name, "graph") == 0) {  // candidates: hipGraph replay -- 1 a chain (N <= 1024), 2 the real DAG (N <= 8192), 0 streams
-    if (value < 0 || value > 2) return fail(h, GOGP_EARG, "graph must be 0..2");
+    if (value < 0 || value > 3) return fail(h, GOGP_EARG, "graph must be 0..3");
     h->use_graph = (int)value;
     h->graph_failed = false;
     drop_cand_graph(h);

@@ -27,9 +27,17 @@ struct GraphRec {
   std::unordered_map<hipEvent_t, std::vector<hipGraphNode_t>> evnodes; // what an event stands for
   hipError_t err = hipSuccess;
   int nodes = 0;
+  // diagnostic form (option graph = 3): ONE chain in enqueue order -- every node depends on the node added before it,
+  // whatever its stream (a linear extension of the DAG: the stream path's enqueue order)
+  bool chain = false;
+  hipGraphNode_t glast = nullptr;
   // dependencies of the next node on stream s; clears the pending list
   std::vector<hipGraphNode_t> deps(hipStream_t s) {
     std::vector<hipGraphNode_t> d;
+    if (chain) {
+      if (glast) d.push_back(glast);
+      return d;
+    }
     auto l = last.find(s);
     if (l != last.end() && l->second) d.push_back(l->second);
     auto p = pend.find(s);
@@ -47,6 +55,7 @@ struct GraphRec {
     if (e != hipSuccess && err == hipSuccess) err = e;
     if (e == hipSuccess) {
       last[s] = n;
+      glast = n;
       ++nodes;
     }
   }

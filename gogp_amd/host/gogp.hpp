@@ -158,7 +158,8 @@ class GP {
   }
 
   // gogp_set_option (no reference counterpart), e.g. ("gradient_precision", 32): Observe's LML, Alpha and Produce stay
-  // fp64, what only Gradient needs runs on the fp32 matrix cores
+  // fp64, what only Gradient needs runs on the fp32 matrix cores (one-term kernels with an output scale only: refused --
+  // an exception -- for sums of terms, whose scale components would come off the float K^-1 at 1.9e-4)
   void SetOption(const char *name, int64_t value) { check(gogp_set_option(h_, name, value)); }
 
   gogp_handle *handle() { return h_; }

@@ -370,7 +370,8 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          2: an explicitly built graph -- one node per launch / copy, the sweep's real
  *                          cross-stream dependencies as edges, no stream capture -- up to N = 8192:
  *                          bit-identical to the stream path and, on this runtime, slower than it (DESIGN.md
- *                          section 4); 0: streams                                           (default 1)
+ *                          section 4); 3: the same recorder as ONE chain in enqueue order (diagnostics);
+ *                          0: streams                                                       (default 1)
  *   "produce_tinv", "produce_panels", "produce_groups", "produce_small_below"
  *                          gogp_produce: whole super-panels of `produce_panels` 256-column panels solved through
  *                          the inverse of the factor's diagonal block (1) or panel by panel (0); the test
@@ -378,10 +379,20 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          below that many 128-tiles                                  (default 1, 4, 2, 1024)
  *   "gradient_precision" 64 | 32   on an fp64 handle: 32 runs what only the gradient needs -- Y = L^-T and
  *                          K^-1 = Y Y^T, 2/3 of an evaluation's flops -- on the fp32 tile kernel from a float copy of
- *                          the fp64 factor; factorisation, LML, alpha and Produce stay fp64 bit for bit (default 64)
+ *                          the fp64 factor; factorisation, LML, alpha and Produce stay fp64 bit for bit (default 64).
+ *                          Offered for kernels of ONE term with an output scale (GOGP_EARG otherwise): there the
+ *                          cancelling components come from closed forms and the gradient stays ~1e-8 from the fp64
+ *                          one (1e-6 from the oracle in the tests); a sum of terms would read its scale components
+ *                          off the float K^-1 (1.9e-4 measured), beyond the reference's own 1e-4 (gp_test.go:170,248)
  *   "trace_fp64"   1 | 0   float K^-1 (precision = 32, gradient_precision = 32): tr(alpha alpha^T - K^-1) summed in
  *                          fp64 from Y and the output-scale component from its closed form          (default 1)
  *   "krag"         1 | 0   the triangular inverse's updates skip the zero triangle of a super-panel of Y (default 1)
+ *   "chain_split"  -1 | 0 | 1   fp64: the 256 x 256 diagonal block as two 128-halves (factor + inverse each) with the
+ *                          products between them on the tile kernel for all rows of the panel and X10 of the block
+ *                          inverse formed off the chain; -1: where the evaluation is latency-bound (N <= 8192) or no
+ *                          fp64 inverse runs beside the factorisation (Absorb, eager = 0)             (default -1)
+ *   "produce_small_max" 0..64   gogp_produce with up to this many test points: ONE persistent launch that reads the
+ *                          factor once (trsm_small.hip) instead of the tile-kernel chain; 0: never  (default 64)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 

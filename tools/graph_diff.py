@@ -11,7 +11,7 @@ g = G.GP(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=X, Y=y)
 base = np.log([1.0, 0.6, 0.1])
 xs = np.array([base + 0.02 * c for c in range(k)])
 res = {}
-for mode in (0, 1, 2):
+for mode in (0, 1, 2, 3):
     g.set_option("graph", mode)
     outs = []
     for r in range(4):
@@ -20,5 +20,5 @@ for mode in (0, 1, 2):
     print("mode", mode, "nodes", g.graph_info(), "lml", outs[-1][0], "grad0", outs[-1][1][0])
     print("   calls equal among themselves:", [bool(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])) for o in outs])
     res.setdefault(mode, outs[-1])
-for m in (1, 2):
+for m in (1, 2, 3):
     print("mode %d vs 0: lml diff %s grad diff %s" % (m, res[m][0] - res[0][0], np.abs(res[m][1] - res[0][1]).max()))

@@ -17,7 +17,7 @@ for N in Ns:
         if k > 1 and N > 4096:
             continue
         ref = None
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             if mode == 1 and N > 1024:
                 continue
             g.set_option("graph", mode)

@@ -28,7 +28,11 @@ while time.time() < t_end:
         g.set_option(ov.split("=")[0], int(ov.split("=")[1]))
     mixed = prec == 64 and rng.integers(0, 5) == 0   # one fp64 handle in five with the inverse in fp32 (option
     if mixed:                                        # gradient_precision = 32): LML / mu / sigma bounds stay fp64's
-        g.set_option("gradient_precision", 32)
+        try:
+            g.set_option("gradient_precision", 32)
+        except G.GogpError:                          # refused for sums of terms / kernels without an output scale (round 5)
+            assert len(getattr(simil, "terms", [simil])) > 1 or name in ("hyperpriors", "periodic_sum", "normal1d")
+            mixed = False
     tol = {"lml": 1e-8, "grad": 1e-6, "mu": 1e-6, "sigma": 1e-5} if prec == 64 else \
           {"lml": 3e-4, "grad": 3e-3, "mu": 3e-2, "sigma": 3e-3}  # fp32: errors follow the conditioning.  Round 3
                                                                    # widened grad to 1e-2 for seed 7 (matern32, n = 1721,
@@ -37,7 +41,8 @@ while time.time() < t_end:
     if mixed:
         # the reference's own gradient tolerance (gp_test.go:170,248) for kernels with ONE term, whose cancelling
         # components come from closed forms; sums of terms have no closed form per term: 1.9e-4 seen (hyperpriors, n = 1365)
-        tol = dict(tol, grad=1e-4 if len(getattr(simil, "terms", [simil])) == 1 and name not in ("hyperpriors", "periodic_sum") else 1e-3)
+        # (round 4 allowed 1e-3 for sums of terms -- 1.9e-4 seen; round 5: the option is refused for them instead)
+        tol = dict(tol, grad=1e-4)
     o = FastOracle(D, simil, noise)
     for rep in range(int(rng.integers(1, 5))):       # the same handle with changing data sizes
         n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000)]))
