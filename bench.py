@@ -211,7 +211,7 @@ def pmc_traffic(config, build_id):
     it was measured on (gogp_version(): hash of the library's sources); with another build the number is
     stale and is NOT reported.  Returns (entry or None, reason)."""
     d = None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest round's file that exists
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest round's file that exists
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -662,7 +662,7 @@ def main():
         build_id = version.split("build ")[-1] if "build " in version else "unknown"
         out["library"] = version
         tr, why = pmc_traffic(wl.config, build_id)
-        if tr is not None and tr.get("N") == N and not sharded_value:
+        if tr is not None and tr.get("N") == N and not sharded_value and tr.get("candidates_per_step", 1) == cps:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_note"] = tr.get("note")
         else:

@@ -781,11 +781,12 @@ static void mixed_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
 // chain launch costs its dispatch (wg_stamps: 80 of 144 us for a K = 256 panel solve at N = 16384), so more launches lose.
 // Measured (tools/split_probe.py): Observe + Gradient N = 1024 0.89 -> 0.84 ms, 2048 1.65 -> 1.46, 4096 3.50 -> 3.25, 8192
 // 12.2 -> 12.2, 16384 72.2 -> 73.0; the Cholesky alone (eager = 0) 4096 3.28 -> 2.72, 8192 8.2 -> 7.3, 16384 33.3 -> 31.9:
-// so also on at any size when no fp64 inverse runs beside the factorisation (Absorb, eager = 0, the mixed gradient).
+// so also on at any size when no inverse runs beside the factorisation (Absorb, eager = 0).  (Not for the mixed gradient
+// above that size: its LML is promised to be the native path's bit for bit.)
 static inline bool chain_split_of(const gogp_handle *h, bool eager) {
   if (h->dist || h->prec != 64) return false;
   if (h->chain_split >= 0) return h->chain_split != 0;
-  return h->npad <= 8192 || !eager || (h->grad_prec == 32 && !h->batch_mode);
+  return h->npad <= 8192 || !eager;
 }
 static void split_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, double *Dp, int64_t ld, int64_t c0,
                         int64_t npad, GemmProfile *pf) {

@@ -102,11 +102,9 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   const int wg = blockIdx.x;
   const int B = wg / TS_WPB, sub = wg - B * TS_WPB;
   const long r0 = (long)wg * TS_RT + 16 * w;  // first row of this wave
-  // 64-column chunks of this workgroup: L[rows, 0:256 B], then ALL FOUR of Dinv_B[rows, 0:256].  The chunks right of
-  // the diagonal (c > sub) are zeros and add nothing, but a ring slot that is never read again is a register hipcc
-  // hands to the reduction / publishing code behind the loop -- which then waits for the load still in flight into it
-  // (a write-after-write wait of one full HBM latency, 2.5 us, on the critical path of every block: tools/trsv_stamps.py)
-  const int nc = 4 * B + 4;
+  // 64-column chunks of this workgroup: L[rows, 0:256 B] (4 B of them), then ALL FOUR of Dinv_B[rows, 0:256]: the chunks
+  // right of the diagonal (c > sub) are zeros and add nothing, but every ring slot stays in use to the end -- a slot that
+  // is never read again is a register hipcc hands to other code, which then waits for the load still in flight into it
 
   // ---- operand ring: chunk q -> this lane's eight 16-B pieces --------------------------------------
   const double *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
@@ -128,10 +126,10 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   // (chunk indices are clamped to the last one instead of guarded: a conditional load makes every ring register a
   // phi of "old or new" and hipcc then keeps both -- 137 VGPR spills in the one-right-hand-side kernel; the repeated
   // load of the last chunk lands in a slot nobody reads any more)
-  issue(0, ar[0]);
-  issue(min(1, nc - 1), ar[1]);
-  issue(min(2, nc - 1), ar[2]);
-  issue(min(3, nc - 1), ar[3]);
+  issue(0, ar[0]);  // chunks 0 .. 3: block 0 of L, or (B = 0) this workgroup's rows of Dinv_0 themselves
+  issue(1, ar[1]);
+  issue(2, ar[2]);
+  issue(3, ar[3]);
 
 
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.Vk, 0, (int)((long)g.nb * PANEL * MC * 8), 0x00020000);
@@ -210,30 +208,36 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   };
 
   // ---- blocks j < B: acc += L[rows, block j] v_j --------------------------------------------------------
-  int q = 0;
-  for (int j = 0; j < B; ++j) {
+  // A block's four chunks are multiplied FIRST and the next block's 32 loads per wave requested behind them (the ring
+  // is exactly one block: all four slots are free then).  Interleaved, every load instruction waited for room in the
+  // compute unit's memory pipeline (~40 GB/s per unit) with the next chunk's MFMAs behind it in program order: 3.6 us
+  // per block (measured on the one-right-hand-side kernel by leaving the loads out).  The last block requests nothing
+  // before w is published: the drain of the write-through stores would wait for those loads too.
+  auto issue_block = [&](int qb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) issue(qb + c, ar[c]);
+  };
+  auto block_step = [&](int j) -> bool {
     if (tid == 0) ok_s = wait_count(g.done + j, TS_WPB, g.tmo, 0x100u + (unsigned)wg) ? 1 : 0;
     __syncthreads();  // the poll has matched; everybody is done with the previous block in LDS
-    if (!ok_s) return;
+    if (!ok_s) return false;
     stage(false, j);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c, ++q) {
-      chunk_mma(c, ar[c], acc);
-      // the slot just consumed takes the chunk FOUR ahead: when a block is done, the whole next block is in flight --
-      // with the request in front of the multiplication (three ahead) the last chunk of every block was only asked
-      // for once v_j had arrived, and its HBM latency sat on the substitution's critical path (tools/trsv_stamps.py:
-      // 3.7 us per block for a 0.3 us phase)
-      issue(min(q + 4, nc - 1), ar[c]);
-    }
+    for (int c = 0; c < 4; ++c) chunk_mma(c, ar[c], acc);
+    return true;
+  };
+  for (int j = 0; j < B - 1; ++j) {
+    if (!block_step(j)) return;
+    issue_block(4 * (j + 1));
   }
+  if (B > 0 && !block_step(B - 1)) return;
   // ---- diagonal step: publish w, wait for the block's other parts, v_rows = Dinv_B[rows, :] w_B -----------
   publish(g.Wk, acc, -1.0);
   __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(g.cnt + B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok_s = wait_count(g.cnt + B, TS_WPB, g.tmo, 0x200u + (unsigned)wg) ? 1 : 0;
-  }
+  if (tid == 0) __hip_atomic_fetch_add(g.cnt + B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (B > 0) issue_block(4 * B);  // this workgroup's rows of Dinv_B: they land while the block's w parts travel
+  if (tid == 0) ok_s = wait_count(g.cnt + B, TS_WPB, g.tmo, 0x200u + (unsigned)wg) ? 1 : 0;
   __syncthreads();
   if (!ok_s) return;
   stage(true, B);
@@ -303,14 +307,28 @@ unsigned long long *g_ts_stamps = nullptr;
   } while (0)
 
 // Five waves: waves 0..3 stream L and do the arithmetic (16 rows each), wave 4 is the COURIER -- it issues no other
-// memory instruction than the sweeps.  Vector loads return in order per wave, so a poll issued by a streaming wave comes
-// back only behind the 24 KB of L that wave has in flight (2-3 us under load, per hop: measured 7.9 us per block with
-// the polls on the streaming waves); the courier's polls only pay the CU's memory queue.  It also runs one block ahead:
-// v_{j+1} is swept into the other half of a double buffer while the streaming waves multiply v_j.
+// memory instruction than the sweeps and runs one block ahead: v_{j+1} is swept into the other half of a double buffer
+// while the streaming waves multiply v_j.
+// What a block step costs was measured piece by piece (tools/trsv_stamps.py, and builds with single pieces left out): the
+// two hops 0.85 + 1.3 us, the arithmetic 0.3 + 0.3 us -- and 3.6 us for ISSUING the next block's 32 loads per wave between
+// the multiply-adds: one compute unit takes in ~40 GB/s, a load instruction does not issue before the memory pipeline has
+// room, and the wave's next multiply-add waits behind it in program order.  So (1) a block's four chunks are multiplied
+// FIRST and the next block's loads requested behind them (the ring is exactly one block: all four slots are free then),
+// the last block requests nothing; (2) this workgroup's rows of Dinv_B do not go through the ring at all: each streaming
+// wave sends its 16 rows x 64 (sub + 1) columns global -> LDS (LDS-DMA, no registers) before anything else, in the very
+// lane order the diagonal step reads them back.  128 KB of LDS: one workgroup per compute unit (N = 16384: 256 workgroups).
+__device__ __forceinline__ void ts_load16_to_lds(const double *gsrc, double *lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(gsrc, lds_wave_base, 16, 0, 0);
+#endif
+}
+constexpr int TS_DINV_LDS = 4 * 4 * 8 * 128;  // doubles: [wave][chunk][piece] images of 64 lanes x 16 B
 __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
-  __shared__ __attribute__((aligned(16))) double vs[2][PANEL];
-  __shared__ double red[4];
-  __shared__ int fail_s;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double *dl = dyn;                                         // Dinv rows, TS_DINV_LDS doubles
+  double(*vs)[PANEL] = reinterpret_cast<double(*)[PANEL]>(dyn + TS_DINV_LDS);  // [2][256]
+  double *red = dyn + TS_DINV_LDS + 2 * PANEL;              // [4]
+  volatile int &fail_s = *reinterpret_cast<volatile int *>(red + 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool courier = w == 4;
@@ -318,7 +336,6 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   const int wg = blockIdx.x;
   const int B = wg / TS_WPB, sub = wg - B * TS_WPB;
   const long r0 = (long)wg * TS_RT + 16 * (courier ? 0 : w);
-  const int nc = 4 * B + 4;  // all four chunks of Dinv's rows (zeros right of the diagonal): see trsm_small_kernel
   const double *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
   const double *Drow = g.Dinv + (long)B * PANEL * PANEL + (long)(sub * TS_RT + 16 * (courier ? 0 : w) + fr) * PANEL + 2 * fk;
   const auto vsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.Vg, 0, (int)((long)g.nb * PANEL * 16), 0x00020000);
@@ -382,27 +399,23 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   }
 
   // ---- streaming waves ----------------------------------------------------------------------------------------------
-  f64x2 ar[4][8];
-  auto issue = [&](int q, f64x2(&slot)[8]) {
-    const double *p = (q < 4 * B) ? Lrow + (long)q * 64 : Drow + (long)(q - 4 * B) * 64;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) slot[i] = *reinterpret_cast<const f64x2 *>(p + 8 * i);
-  };
-  // (chunk indices are clamped to the last one instead of guarded: a conditional load makes every ring register a
-  // phi of "old or new" and hipcc then keeps both -- 137 VGPR spills; the repeated load of the last chunk lands in a
-  // slot nobody reads any more)
-  // the right-hand side FIRST: vector loads return in order, so every later wait for a ring slot also covers it.  Loaded
-  // behind the ring's first requests, hipcc guarded its use after the loop with an s_waitcnt vmcnt(22) -- which, with the
-  // next block's 32 requests just issued, waits for ten of THEM: one full HBM latency (2.5 us) on the critical path of every
-  // block (tools/trsv_stamps.py: 3.6 us for a 0.8 us phase)
+  // the right-hand side FIRST (vector loads return in order: every later wait also covers it), then this wave's rows of
+  // Dinv_B straight into LDS: piece (c, i) = 16 rows x 64 B, the lanes in the order the diagonal step reads them back
   const double brow = g.b[r0 + fr];
-  issue(0, ar[0]);
-  issue(min(1, nc - 1), ar[1]);
-  issue(min(2, nc - 1), ar[2]);
-  issue(min(3, nc - 1), ar[3]);
+  double *dlw = dl + w * (4 * 8 * 128);
+  for (int c = 0; c <= sub; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ts_load16_to_lds(Drow + c * 64 + 8 * i, dlw + (c * 8 + i) * 128);
+  f64x2 ar[4][8];
+  auto issue_block = [&](int j) {  // the four chunks of L[rows, block j] into the four ring slots
+    const double *p = Lrow + (long)j * PANEL;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ar[c][i] = *reinterpret_cast<const f64x2 *>(p + c * 64 + 8 * i);
+  };
   // this wave's 16 rows of one 64-column chunk c of the staged block: lane (fr, fk) adds its 16 of the 64 columns
-  // (the chunk's eight LDS reads first, then two independent chains of eight multiply-adds: one chain of 64 dependent
-  // fp64 operations per block, each behind its own LDS wait, was most of the 3.3 us this phase took)
+  // (the chunk's eight LDS reads first, then two independent chains of eight multiply-adds)
   auto chunk_fma = [&](const double *buf, int c, const f64x2(&slot)[8], double &acc) {
     f64x2 vv[8];
 #pragma unroll
@@ -431,29 +444,40 @@ __global__ __launch_bounds__(320) void trsv_granule_kernel(T1Args g) {
   };
 
   double acc = 0.0;
-  int q = 0;
-  for (int j = 0; j < B; ++j) {
-    __syncthreads();  // v_j is in vs[j & 1]
-    if (fail_s) return;
-    const double *buf = vs[j & 1];
+  if (B > 0) {
+    issue_block(0);
+    for (int j = 0; j < B - 1; ++j) {
+      __syncthreads();  // v_j is in vs[j & 1]
+      if (fail_s) return;
+      const double *buf = vs[j & 1];
 #pragma unroll
-    for (int c = 0; c < 4; ++c, ++q) {
-      chunk_fma(buf, c, ar[c], acc);
-      issue(min(q + 4, nc - 1), ar[c]);  // four ahead, into the slot just consumed (see trsm_small_kernel)
+      for (int c = 0; c < 4; ++c) chunk_fma(buf, c, ar[c], acc);
+      issue_block(j + 1);  // behind the arithmetic, all four slots being free: see the kernel's header
     }
+    __syncthreads();  // the last block of L: nothing is requested behind it
+    if (fail_s) return;
+    const double *buf = vs[(B - 1) & 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) chunk_fma(buf, c, ar[c], acc);
   }
   acc += __shfl_xor(acc, 16);
   acc += __shfl_xor(acc, 32);
   publish(true, brow - acc);
   if (w == 0) TS_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows of Dinv_B are in LDS (requested first: long there)
   __syncthreads();  // (nothing to order for the granules themselves: this releases the courier's sweep of w_B)
   __syncthreads();  // w_B is in vs[B & 1]
   if (fail_s) return;
   double res = 0.0;
   {
+    // the chunks 0 .. sub of Dinv's rows (lower triangular: zeros right of the diagonal), from LDS
     const double *buf = vs[B & 1];
+    for (int c = 0; c <= sub; ++c) {
+      f64x2 dv[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) chunk_fma(buf, c, ar[c], res);
+      for (int i = 0; i < 8; ++i) dv[i] = *reinterpret_cast<const f64x2 *>(dlw + (c * 8 + i) * 128 + 2 * lane);
+      chunk_fma(buf, c, dv, res);
+    }
   }
   res += __shfl_xor(res, 16);
   res += __shfl_xor(res, 32);
@@ -488,7 +512,14 @@ static void launch_trsv_granule(hipStream_t s, const double *L, int64_t ld, cons
   g.nb = nb;
   g.stamps = g_ts_stamps;
   if (tmo_dev) *tmo_dev = g.tmo;
-  GOGP_KLAUNCH(trsv_granule_kernel, dim3(nwg), dim3(320), 0, s, g);
+  const size_t lds = (size_t)(TS_DINV_LDS + 2 * PANEL + 4 + 2) * sizeof(double);
+  static bool raised = false;  // 132 KB of dynamic LDS: above the default limit
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_granule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    raised = true;
+  }
+  GOGP_KLAUNCH(trsv_granule_kernel, dim3(nwg), dim3(320), lds, s, g);
   GOGP_KLAUNCH(trsm_small_finish_kernel, dim3(1), dim3(64), 0, s, (const double *)g.sqpart, nwg, 1, 1, 0, dq);
 }
 

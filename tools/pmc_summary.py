@@ -11,7 +11,7 @@ def short(n):
     m = re.search(r'sgemm_nt_kernel<(\d), (\d+), (\d)>', n)
     if m:  # MODE, TILE, WAVES
         return 'sgemm_nt_kernel<%s, %s, %s>' % m.group(1, 2, 3)
-    for k in ['diag256', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y', 'zero_upper', 'kmatvec', 'convert_block',
+    for k in ['diag256', 'diag128', 'trsv_granule', 'trsm_small', 'blockmm', 'trsv_fwd', 'trsv_bwd', 'grad_reduce', 'gram_kernel', 'alpha_from_y', 'zero_upper', 'kmatvec', 'convert_block',
               'mfma_f64_peak', 'mfma_f32_peak']:
         if k in n:
             return k
