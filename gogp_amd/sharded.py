@@ -107,9 +107,7 @@ class ShardedGP(GP):
         elif transport == "replay":
             # measurement only (tools/sharded_replay.py): this object is rank `rank` of the grid ALONE on its GPU; the
             # hook library installs a transport that sends nothing and zero-fills what would have been received
-            hooks = ctypes.CDLL(_lib.HOOKS_PATH)
-            hooks.gogp_test_dist_init_replay.restype = ctypes.c_int
-            hooks.gogp_test_dist_init_replay.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+            hooks = _lib.hooks()
             self._check(hooks.gogp_test_dist_init_replay(self._h, self._rank, self._world, self.grid[0], self.grid[1]))
         else:
             raise ValueError("transport must be 'rccl', 'callbacks' or 'replay'")
