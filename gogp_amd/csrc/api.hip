@@ -783,10 +783,13 @@ static void mixed_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
 // 12.2 -> 12.2, 16384 72.2 -> 73.0; the Cholesky alone (eager = 0) 4096 3.28 -> 2.72, 8192 8.2 -> 7.3, 16384 33.3 -> 31.9:
 // so also on at any size when no inverse runs beside the factorisation (Absorb, eager = 0).  (Not for the mixed gradient
 // above that size: its LML is promised to be the native path's bit for bit.)
-static inline bool chain_split_of(const gogp_handle *h, bool eager) {
-  if (h->dist || h->prec != 64) return false;
-  if (h->chain_split >= 0) return h->chain_split != 0;
-  return h->npad <= 8192 || !eager;
+// 2: the chain per 128 columns is ONE launch (panel128.hip: every workgroup factors the diagonal 128-block redundantly
+// and forward-substitutes its own 64 panel rows on the way: no block inverse and no solve launch on the chain); the
+// 256 x 256 block inverses are formed off the chain from the finished factor (dinv_blocks below).
+static inline int chain_split_of(const gogp_handle *h, bool eager) {
+  if (h->dist || h->prec != 64) return 0;
+  if (h->chain_split >= 0) return h->chain_split;
+  return (h->npad <= 8192 || !eager) ? 2 : 0;
 }
 static void split_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, double *Dp, int64_t ld, int64_t c0,
                         int64_t npad, GemmProfile *pf) {
@@ -807,6 +810,23 @@ static void split_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, do
                    L + c2 * ld + c1, ld, pf, &gtri);
 }
 static void split_panel(gogp_handle *, hipStream_t, float *, float *, float *, int64_t, int64_t, int64_t, GemmProfile *) {}
+// chain_split = 2: panel128 (half 0) -> A[c1:, c1:c2] -= L[c1:, c0:c1] L[c1:c2, c0:c1]^T (tile kernel) -> panel128 (half 1)
+static void fused_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, int64_t ld, int64_t c0, int64_t npad,
+                        GemmProfile *pf) {
+  const int64_t c1 = c0 + TILE, c2 = c0 + PANEL;
+  const int mt1 = (int)((npad - c1) / TILE);
+  GemmGrid gch;
+  gch.prio = chain_prio_of(h);
+  launch_panel128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 0, npad - c1, c0, h->n, h->info);
+  launch_gemm_nt(sp, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0, ld, 1.0, A + c1 * ld + c1, ld,
+                 pf, &gch);
+  launch_panel128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 1, npad - c2, c0, h->n, h->info);
+}
+static void fused_panel(gogp_handle *, hipStream_t, float *, float *, int64_t, int64_t, int64_t, GemmProfile *) {}
+static void dinv_blocks(hipStream_t s, const double *L, double *Dinv, int64_t ld, int P0, int nsub) {
+  launch_dinv256_blocks(s, L + (int64_t)P0 * PANEL * (ld + 1), ld, Dinv + (size_t)P0 * PANEL * PANEL, nsub);
+}
+static void dinv_blocks(hipStream_t, const float *, float *, int64_t, int, int) {}
 // X10 = -X11 (L10 X00) for the nsub diagonal blocks of a super-panel: two batched 128^3 products (solve.hip:
 // blockmm_kernel); M = L10 X00 goes through the block's A10 position in bufA, which is dead once split_panel has read it
 static void x10_blocks(gogp_handle *h, hipStream_t s, double *A, const double *L, double *Dinv, int64_t ld, int P0, int nsub) {
@@ -916,7 +936,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
-  const bool split = std::is_same<T, double>::value && chain_split_of(h, eager);
+  const int split = std::is_same<T, double>::value ? chain_split_of(h, eager) : 0;
   if (!h->batch_mode) h->tinv_valid = false;  // Produce assembles T^-1 of the new factor on its first call
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
@@ -940,7 +960,9 @@ static int factorize_t(gogp_handle *h, bool eager) {
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
       T *Dp = Dinv + (size_t)p * PANEL * PANEL;
       const int mt2 = (int)((npad - c2) / TILE);
-      if (split) {
+      if (split == 2) {
+        fused_panel(h, sp, A, L, ld, c0, npad, pf);
+      } else if (split) {
         // option "chain_split": the two 128 x 128 halves of the diagonal block are factored and inverted on their own
         // (diag256.hip: diag128_kernel) and the three products between them -- which the 256-block kernel does on ONE
         // compute unit -- go to the tile kernel for ALL rows of the panel at once: they are the panel solve and the
@@ -979,9 +1001,12 @@ static int factorize_t(gogp_handle *h, bool eager) {
     if (sz != sp) (void)gogp::rec_stream_wait(sz, ev(h, EV_BASE + 4 * P0));
 
     if (split) {
-      // X10 = -X11 (L10 X00) of the super-panel's diagonal blocks, off the chain: the substitution steps right below and
-      // the triangular inverse (st) are its first readers
-      x10_blocks(h, sz, A, L, Dinv, ld, P0, nsub);
+      // X10 = -X11 (L10 X00) of the super-panel's diagonal blocks (chain_split = 2: their whole inverses), off the chain:
+      // the substitution steps right below and the triangular inverse (st) are its first readers
+      if (split == 2)
+        dinv_blocks(sz, L, Dinv, ld, P0, nsub);
+      else
+        x10_blocks(h, sz, A, L, Dinv, ld, P0, nsub);
       if (eager) {
         (void)gogp::rec_event_record(ev(h, EV_BASE + 5 * (size_t)npanel + 32 + (size_t)P0), sz);
         (void)gogp::rec_stream_wait(st, ev(h, EV_BASE + 5 * (size_t)npanel + 32 + (size_t)P0));
@@ -2426,7 +2451,7 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     return GOGP_OK;
   }
   if (strcmp(name, "chain_split") == 0) {  // -1: by size, 0: 256-block kernel, 1: two 128-halves + products on the tile kernel
-    if (value < -1 || value > 1) return fail(h, GOGP_EARG, "chain_split must be -1..1");
+    if (value < -1 || value > 2) return fail(h, GOGP_EARG, "chain_split must be -1..2");
     h->chain_split = (int)value;
     return GOGP_OK;
   }

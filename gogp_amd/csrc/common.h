@@ -233,6 +233,12 @@ void launch_diag256_ld512(hipStream_t s, const double *A, int64_t ld, double *Lo
 void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv, int half,
                     int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_inv_only(hipStream_t s, const double *L, int64_t ld, double *Dinv);
+// panel128.hip (option "chain_panel"): one 128-column step of the Cholesky chain in one launch -- the diagonal 128-block of
+// half 0 / 1 of the 256-block at A is factored and the rows_below (multiple of 64) rows under it are solved against it
+void launch_panel128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, int half, int64_t rows_below,
+                     int64_t row0, int64_t nvalid, long long *info);
+// dense inverses of nblk consecutive 256 x 256 diagonal blocks of a finished factor (block b at L + b * 256 * (ld + 1))
+void launch_dinv256_blocks(hipStream_t s, const double *L, int64_t ld, double *Dinv, int nblk);
 void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv);  // Dinv: ld 512
 void launch_convert_block(hipStream_t s, const double *src, int64_t lds_, double *dst, int64_t ldd, int rows,
                           int cols);

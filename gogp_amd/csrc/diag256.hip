@@ -18,9 +18,9 @@
 // (upper zero-filled), which turns every panel solve of the callers into a
 // single K=256 GEMM  (panel) * Dinv^T.
 //
-// chol(128) is blocked by 16 (potrf128_lds): per column block, three waves factor the 16x16
-// diagonal block and solve the rows below it in ONE pass (panel16: the panel rows ride in
-// lanes 16..63 of the factoring wave), five waves apply the previous panel to the rest of the
+// chol(128) is blocked by 16 (potrf128_lds): per column block, two waves factor the 16x16
+// diagonal block and solve the rows below it in ONE pass (panel16, pivot16.h: one lower row per
+// lane beside the replicated block), six waves apply the previous panel to the rest of the
 // matrix with MFMA.  The 128x128 inverse is assembled from the eight 16x16 inverses by
 // recursive doubling (X21 = -X22 L21 X11 at sizes 16, 32, 64) on MFMA.  The four 128^3
 // products (L10, Schur complement, U = X11 L10, X10 = -U X00) skip the zero blocks of their
@@ -38,6 +38,7 @@
 // 2 k hit 64 distinct banks), G = 2304 doubles: the eight 16x16 inverses during the factor /
 // inverse phases, the double-buffered B chunks during the products.
 #include "common.h"
+#include "pivot16.h"
 
 // The test-hook library compiles this file a second time into its own namespace
 // (-DGOGP_NS=gogp_th -DGOGP_BUILD_TESTHOOKS) to get the stamped diagnostic build of the
@@ -71,56 +72,49 @@ __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// Column block kb of the 128x128 matrix in S, factored AND solved by one wave in one pass:
-// lanes 0..15 own row r of the 16x16 diagonal block (right-looking Cholesky with
-// v_readlane broadcasts; 1/sqrt by v_rsq_f64 + two Newton steps), lanes 16..63 own 48 of
-// the rows below it (row0 + lane - 16, rows >= 128 idle) and execute the SAME instructions:
-// scaling by 1/L_jj and the rank-1 update with the broadcast pivot-row values is exactly the
-// forward substitution of their row against the block, so the panel solve costs nothing on
-// top of the factorisation.  Waves that only carry panel rows redo the diagonal block
-// redundantly (write_diag = false).  Writes the factor block (upper zeroed), 1/L_jj to
-// rinv[0..15] (LDS) and the solved rows back to S; the columns form one basic block (the
-// not-positive-definite test is branch-free and reported once at the end).
-// The factored diagonal block is NOT written here: the other waves of the step read the
-// unfactored block at the start of their own pass, so wave 0 keeps its rows (keep[], mine)
-// and stores them with panel16_store_diag after the next barrier.
+// Column block kb of the 128x128 matrix in S, factored AND solved by one wave in one pass (pivot16.h): every lane owns
+// row lane & 15 of the 16x16 diagonal block (ad; the block is replicated in the wave's four rows of 16 lanes, so the pivot
+// column's values reach every lane by a DPP broadcast inside its own row) AND row row0 + lane below it (ap; lanes past row
+// 127 carry copies of that row) -- scaling by 1/L_jj and the rank-1 update with the broadcast pivot-column values is
+// exactly the forward substitution of the lower row against the block, so the panel solve costs nothing on top of the
+// factorisation.  Every wave of the step redoes the diagonal block (the same operations in the same order: the same
+// bits).  Writes the solved rows back to S; the not-positive-definite test is branch-free and reported once at the end.
+// The factored diagonal block is NOT written here: the other waves of the step read the unfactored block at the start
+// of their own pass, so wave 0 keeps its rows (keep[], mine = 1/L_rr of lane r) and stores them with panel16_store_diag
+// after the next barrier.  (Until round 5 the broadcasts were v_readlane pairs through SGPRs -- a third of the pass's
+// instructions -- 48 lower rows per wave in lanes 16..63, and the update of each column was left to the column that
+// needed it: a second dependent chain.  tools/panel_probe.py: 16 columns in ~4.2K cycles against ~5.8K.)
 __device__ __forceinline__ void panel16(double *S, int kb, int lane, int row0, bool report,
                                         long grow0, long nvalid, long long *info,
                                         double (&keep)[16], double &keep_rinv) {
   const int r = lane & 15;
-  const bool prow = lane >= 16;                      // panel-row lane
-  const int row = prow ? row0 + lane - 16 : kb * 16 + r;
-  const bool live = row < 128;
-  double a[16];
-  double *src = S + (live ? row : 127) * SLD + kb * 16;
+  const int prow = row0 + lane;
+  const double *srcd = S + (kb * 16 + r) * SLD + kb * 16;
+  double *srcp = S + (prow < 128 ? prow : 127) * SLD + kb * 16;
+  double ap[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) a[c] = src[c];
-  double mine = 0.0;
+  for (int c = 0; c < 16; c += 2) {
+    const f64x2 v = *reinterpret_cast<const f64x2 *>(srcd + c);
+    const f64x2 u = *reinterpret_cast<const f64x2 *>(srcp + c);
+    keep[c] = v.x;
+    keep[c + 1] = v.y;
+    ap[c] = u.x;
+    ap[c + 1] = u.y;
+  }
   int bad = 16;  // first non-positive pivot
+  double mine = 0.0;
+  PivotColumn<0, true>::run(keep, ap, bcast16<0>(keep[0]), 0.0, 0.0, bad, mine, r);
+  // the values are needed HERE: without this hipcc sinks the lower rows' arithmetic (and 1/L_rr) into the branches that
+  // store them, undoing the interleave and keeping every broadcast alive for it (808 VGPR spills)
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const double d = readlane_d(a[j], j);
-    // off the dependency chain: a non-positive (or NaN) pivot is only recorded; its rsq is
-    // NaN/inf and poisons the rest of the factor, which the caller discards (GOGP_ENOTPD)
-    bad = (!(d > 0.0) && bad == 16) ? j : bad;
-    double rs = __builtin_amdgcn_rsq(d);
-#ifndef GOGP_RSQ_NEWTON
-#define GOGP_RSQ_NEWTON 2
-#endif
+  for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(ap[c]));
+  asm volatile("" : "+v"(mine));
+  // every lane stores (an idle lane carries a copy of row 127, whose owner is in this wave and writes the same bits) --
+  // unless the wave has no lower row at all: row 127 then belongs to the diagonal block itself
+  if (row0 < 128) {
 #pragma unroll
-    for (int it = 0; it < GOGP_RSQ_NEWTON; ++it) rs = fma(rs * 0.5, fma(-d * rs, rs, 1.0), rs);
-    mine = (lane == j) ? rs : mine;  // lane j keeps 1/L_jj; stored once below
-    const double lrj = a[j] * rs;    // lane j: d/sqrt(d) = sqrt(d)
-    a[j] = lrj;
-#pragma unroll
-    for (int c = j + 1; c < 16; ++c) a[c] -= lrj * readlane_d(lrj, c);
+    for (int c = 0; c < 16; c += 2) *reinterpret_cast<f64x2 *>(srcp + c) = (f64x2){ap[c], ap[c + 1]};
   }
-  if (prow && live) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) src[c] = a[c];
-  }
-#pragma unroll
-  for (int c = 0; c < 16; ++c) keep[c] = a[c];
   keep_rinv = mine;
   if (report && bad < 16 && lane == 0 && grow0 + bad < nvalid && *info == 0)
     *info = (long long)(grow0 + bad + 1);
@@ -174,8 +168,8 @@ __device__ __forceinline__ void inv16(const double *S, int kb, double *Xb, const
 // In-LDS blocked Cholesky of the 128x128 matrix in S (lower triangle valid, upper
 // zero), block size 16.  Per step kb -> kb+1:
 //   A. the eight waves update column block kb+1 by panel kb (one 16x16 tile each, MFMA);
-//   B. waves 0..2 factor + solve column block kb+1 (panel16: the diagonal block and up to
-//      3 x 48 rows below, one pass), while waves 3..7 apply panel kb to the rest of the
+//   B. waves 0..1 factor + solve column block kb+1 (panel16: the diagonal block and up to
+//      2 x 64 rows below, one pass), while waves 2..7 apply panel kb to the rest of the
 //      trailing matrix (MFMA rank-16 updates) -- off the critical path.
 // The critical path per step is one tile update + one panel16 + two barriers.
 // On exit S = L (upper zero) and XD[kb] = inverse of L's kb-th diagonal block (the
@@ -203,9 +197,9 @@ __device__ __forceinline__ void potrf128_lds(
                              long nvalid, long long *info, unsigned long long *st = nullptr) {
   const int lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  // rows below block kb: (7-kb)*16; wave w < 3 carries rows (kb+1)*16 + 48w .. +47
+  // rows below block kb: (7-kb)*16; wave w < 2 carries rows (kb+1)*16 + 64w .. +63
   double keep[16], keep_rinv = 0.0;
-  if (w < 3) panel16(S, 0, lane, 16 + 48 * w, w == 0, grow0, nvalid, info, keep, keep_rinv);
+  if (w < 2) panel16(S, 0, lane, 16 + 64 * w, w == 0, grow0, nvalid, info, keep, keep_rinv);
   if (st && tid == 0) st[1] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   for (int kb = 0; kb < 7; ++kb) {
@@ -216,16 +210,16 @@ __device__ __forceinline__ void potrf128_lds(
     if (kb + 1 + w < 8) tile_update16(S, kb + 1 + w, kb + 1, kb, fr, fk);
     __syncthreads();
     // ---- B -------------------------------------------------------------------------------
-    if (w < 3) {
-      if ((kb + 2) * 16 + 48 * w < 128 || w == 0)
-        panel16(S, kb + 1, lane, (kb + 2) * 16 + 48 * w, w == 0, grow0 + (kb + 1) * 16, nvalid,
+    if (w < 2) {
+      if ((kb + 2) * 16 + 64 * w < 128 || w == 0)
+        panel16(S, kb + 1, lane, (kb + 2) * 16 + 64 * w, w == 0, grow0 + (kb + 1) * 16, nvalid,
                 info, keep, keep_rinv);
       if (st && tid == 0 && kb < 2) st[kb * 3 + 2] = __builtin_amdgcn_s_memtime();
     } else {
-      // tiles (i, c), kb+2 <= c <= i <= 7, dealt to waves 3..7
+      // tiles (i, c), kb+2 <= c <= i <= 7, dealt to waves 2..7
       const int m = 6 - kb;  // block columns kb+2 .. 7
       const int nt3 = m * (m + 1) / 2;
-      for (int t = w - 3; t < nt3; t += 5) {
+      for (int t = w - 2; t < nt3; t += 6) {
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
         const int cc = t - ii * (ii + 1) / 2;
@@ -687,6 +681,28 @@ __global__ __launch_bounds__(NT) void diag128_kernel(const double *__restrict__ 
     if (half == 0) *reinterpret_cast<f64x2 *>(Dinv + i * 256 + 128 + cc) = (f64x2){0.0, 0.0};
   }
 }
+
+// ---- the dense 256 x 256 inverses of nblk consecutive diagonal blocks of a finished factor, one workgroup each (option
+// "chain_panel", api.hip: the chain no longer forms them; the substitutions, the triangular inverse and Produce do need
+// them).  blockIdx.x = b: the block at L + b * 256 * (ld + 1), its inverse at Dinv + b * 65536.
+__global__ __launch_bounds__(NT) void dinv256_blocks_kernel(const double *__restrict__ L, long ld, double *__restrict__ Dinv,
+                                                             long bstride) {
+  L = gogp::cand(L, bstride);  // candidate batching (common.h: Batch)
+  Dinv = gogp::cand(Dinv, bstride);
+  __shared__ __attribute__((aligned(16))) double S[128 * SLD];
+  __shared__ __attribute__((aligned(16))) double G[GSIZE];
+  __shared__ double rinv_s[8 * 16];
+  const long b = blockIdx.x;
+  diag256_body<false, false, 256>(S, G, rinv_s, L + b * 256 * (ld + 1), ld, nullptr, 0L, Dinv + b * 65536L, 0L, 0L, nullptr,
+                                  nullptr);
+}
+
+#ifndef GOGP_BUILD_TESTHOOKS
+void launch_dinv256_blocks(hipStream_t s, const double *L, int64_t ld, double *Dinv, int nblk) {
+  GOGP_KLAUNCH(dinv256_blocks_kernel, dim3((unsigned)nblk, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s, L, (long)ld, Dinv,
+               gogp::tl_batch.stride);
+}
+#endif
 
 #ifndef GOGP_BUILD_TESTHOOKS
 void launch_diag128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, double *Dinv, int half,

@@ -20,6 +20,8 @@ void launch_diag256(hipStream_t s, const double *A, int64_t ld, double *Lout, in
                     double *Dinv, int64_t row0, int64_t nvalid, long long *info);
 void launch_diag256_stamped(hipStream_t s, const double *A, double *Lout, double *Dinv,
                             long long *info, unsigned long long *stamps);
+void launch_panel128_stamped(hipStream_t s, const double *A, double *Lout, int64_t rows_below, long long *info,
+                             unsigned long long *stamps);
 }
 
 namespace gogp {
@@ -259,6 +261,56 @@ extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, doub
   if (e == hipSuccess) e = hipMemcpy(stamps, dst, 32 * 8, hipMemcpyDeviceToHost);
   if (elapsed_us) *elapsed_us = ms * 1e3;
   (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dD); (void)hipFree(dinfo); (void)hipFree(dst);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
+// Diagnostic: one 128-column chain step (panel128.hip) on a (128 + rows_below) x 128 panel given on the host (row-major,
+// ld = 128; the diagonal block's lower triangle is used): the factor of the diagonal block and the solved rows, 72
+// s_memtime stamps of the diagnostic build, and the HIP-event time of `reps` launches of the product build.
+extern "C" int gogp_test_panel128(int device, const double *A, double *Lout, int64_t rows_below, int reps,
+                                  unsigned long long *stamps, double *elapsed_us) {
+  if (!A || !Lout || !stamps || rows_below < 0 || rows_below % 64 || reps <= 0) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *dA = nullptr, *dL = nullptr;
+  long long *dinfo = nullptr;
+  unsigned long long *dst = nullptr;
+  // the product launcher also zeroes the block right of the diagonal block: it gets a 256-wide matrix
+  const size_t rows = 128 + (size_t)rows_below, nb = rows * 128 * sizeof(double), nb2 = rows * 256 * sizeof(double);
+  // each buffer: the ld = 128 matrix (the stamped build's), then the ld = 256 one (the product launcher's)
+  hipError_t e = hipMalloc(&dA, nb + nb2);
+  if (e == hipSuccess) e = hipMalloc(&dL, nb + nb2);
+  if (e == hipSuccess) e = hipMalloc(&dinfo, 8);
+  if (e == hipSuccess) e = hipMalloc(&dst, 72 * 8);
+  if (e == hipSuccess) e = hipMemcpy(dA, A, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy2D(dA + rows * 128, 256 * sizeof(double), A, 128 * sizeof(double), 128 * sizeof(double), rows,
+                                       hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dinfo, 0, 8);
+  if (e == hipSuccess) e = hipMemset(dst, 0, 72 * 8);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    double *A2 = dA + rows * 128, *L2 = dL + rows * 128;  // the ld = 256 copy (the second halves of both buffers)
+    gogp::launch_panel128(0, A2, 256, L2, 256, 0, rows_below, 0, (int64_t)rows, dinfo);  // warm-up
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) gogp::launch_panel128(0, A2, 256, L2, 256, 0, rows_below, 0, (int64_t)rows, dinfo);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    gogp_th::launch_panel128_stamped(0, dA, dL, rows_below, dinfo, dst);
+    (void)hipDeviceSynchronize();
+    gogp_th::launch_panel128_stamped(0, dA, dL, rows_below, dinfo, dst);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(Lout, dL, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(stamps, dst, 72 * 8, hipMemcpyDeviceToHost);
+  if (elapsed_us) *elapsed_us = ms * 1e3 / reps;
+  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dinfo); (void)hipFree(dst);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
 }

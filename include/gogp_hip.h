@@ -387,10 +387,14 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *   "trace_fp64"   1 | 0   float K^-1 (precision = 32, gradient_precision = 32): tr(alpha alpha^T - K^-1) summed in
  *                          fp64 from Y and the output-scale component from its closed form          (default 1)
  *   "krag"         1 | 0   the triangular inverse's updates skip the zero triangle of a super-panel of Y (default 1)
- *   "chain_split"  -1 | 0 | 1   fp64: the 256 x 256 diagonal block as two 128-halves (factor + inverse each) with the
- *                          products between them on the tile kernel for all rows of the panel and X10 of the block
- *                          inverse formed off the chain; -1: where the evaluation is latency-bound (N <= 8192) or no
- *                          fp64 inverse runs beside the factorisation (Absorb, eager = 0)             (default -1)
+ *   "chain_split"  -1 | 0 | 1 | 2   fp64, the factorisation's dependency chain per 256-panel: 0 one workgroup factors and
+ *                          inverts the 256 x 256 diagonal block, the panel solve is a K = 256 product with that inverse;
+ *                          1 two 128-halves (factor + inverse each) with the products between them on the tile kernel
+ *                          and X10 of the block inverse formed off the chain; 2 per 128 columns ONE launch factors the
+ *                          diagonal 128-block and forward-substitutes every panel row on the way (panel128.hip), the
+ *                          block inverses are formed off the chain from the finished factor; -1: 2 where the
+ *                          evaluation is latency-bound (N <= 8192) or no fp64 inverse runs beside the factorisation
+ *                          (Absorb, eager = 0), 0 otherwise                                          (default -1)
  *   "produce_small_max" 0..64   gogp_produce with up to this many test points: ONE persistent launch that reads the
  *                          factor once (trsm_small.hip) instead of the tile-kernel chain; 0: never  (default 64)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */

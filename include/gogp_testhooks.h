@@ -45,6 +45,13 @@ int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
 int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
                       unsigned long long *stamps, double *elapsed_us);
 
+/* Diagnostic hook for one 128-column step of the Cholesky chain (panel128.hip): a (128 + rows_below) x 128 panel given on
+ * the host (row-major, ld 128, lower triangle of the diagonal block used; rows_below a multiple of 64); returns the factor
+ * of the diagonal block with the solved rows under it (same layout), 72 in-kernel s_memtime stamps of a diagnostic build
+ * and the HIP-event time (us per launch over `reps` launches) of the product build. */
+int gogp_test_panel128(int device, const double *A, double *Lout, int64_t rows_below, int reps,
+                       unsigned long long *stamps, double *elapsed_us);
+
 /* Per-rank replay of a sharded evaluation (tools/sharded_replay.py): makes handle `h` (a
  * gogp_handle of the product library) rank `rank` of a prow x pcol grid ALONE on its GPU -- nothing is sent, a receive
  * zero-fills its buffer, an all-reduce is the identity.  Every launch of that rank's share of the sweep runs with its

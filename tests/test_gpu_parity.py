@@ -521,6 +521,68 @@ def test_kinv_in_two_launches_is_bit_identical(gpmod):
     g.close()
 
 
+@pytest.mark.parametrize("rows_below", [0, 64, 192, 1024])
+def test_chain_step_kernel_against_numpy(rows_below):
+    """panel128.hip alone (gp/gp.go:228, the diagonal-block factorisation and the panel solve of Factorize): the factor of
+    a 128 x 128 block and the rows under it solved against it, against numpy's Cholesky / triangular solve."""
+    import ctypes
+    from gogp_amd import _lib
+    H = _lib.hooks()
+    rng = np.random.default_rng(rows_below + 1)
+    n = 128 + rows_below
+    B = rng.normal(size=(n, 150))
+    K = B @ B.T / 150 + 0.3 * np.eye(n)
+    A = np.ascontiguousarray(K[:, :128])
+    L = np.zeros_like(A)
+    st = (ctypes.c_uint64 * 72)()
+    us = ctypes.c_double()
+    assert H.gogp_test_panel128(0, A.ctypes.data_as(_lib._dp), L.ctypes.data_as(_lib._dp), rows_below, 1, st,
+                                ctypes.byref(us)) == 0
+    Ld = np.linalg.cholesky(K[:128, :128])
+    np.testing.assert_allclose(L[:128], Ld, rtol=0, atol=1e-13 * np.abs(Ld).max())   # upper triangle: zeros
+    if rows_below:
+        ref = np.linalg.solve(Ld, K[128:, :128].T).T
+        np.testing.assert_allclose(L[128:], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("rows_below", [0, 64, 192, 1024])
+def test_chain_step_kernel_against_numpy(rows_below):
+    """panel128.hip alone (gp/gp.go:228, the diagonal-block factorisation and the panel solve of Factorize): the factor of
+    a 128 x 128 block and the rows under it solved against it, against numpy's Cholesky / triangular solve."""
+    import ctypes
+    from gogp_amd import _lib
+    H = _lib.hooks()
+    rng = np.random.default_rng(rows_below + 1)
+    n = 128 + rows_below
+    B = rng.normal(size=(n, 150))
+    K = B @ B.T / 150 + 0.3 * np.eye(n)
+    A = np.ascontiguousarray(K[:, :128])
+    L = np.zeros_like(A)
+    st = (ctypes.c_uint64 * 72)()
+    us = ctypes.c_double()
+    assert H.gogp_test_panel128(0, A.ctypes.data_as(_lib._dp), L.ctypes.data_as(_lib._dp), rows_below, 1, st,
+                                ctypes.byref(us)) == 0
+    Ld = np.linalg.cholesky(K[:128, :128])
+    np.testing.assert_allclose(L[:128], Ld, rtol=0, atol=1e-13 * np.abs(Ld).max())   # upper triangle: zeros
+    if rows_below:
+        ref = np.linalg.solve(Ld, K[128:, :128].T).T
+        np.testing.assert_allclose(L[128:], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def _same_results(a, b):
+    assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-9, atol=1e-9 * np.abs(a[1]).max())
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(b[3], a[3], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(b[4], a[4], rtol=1e-9, atol=1e-9 * np.abs(a[4]).max())
+    np.testing.assert_allclose(b[5], a[5], rtol=0, atol=1e-12 * np.abs(a[5]).max())
+    np.testing.assert_allclose(b[6], a[6], rtol=1e-12)
+    np.testing.assert_allclose(b[7], a[7], rtol=1e-9, atol=1e-9 * np.abs(a[7]).max())
+    assert a[8] == b[8] == [0, 0, 0]
+    np.testing.assert_allclose(b[9], a[9], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(b[10], a[10], rtol=1e-8, atol=1e-11)
+
+
 @pytest.mark.parametrize("n,D", [(1, 1), (129, 1), (700, 2), (1500, 3), (4096, 4)])
 def test_diagonal_block_in_two_halves_matches_the_256_block_kernel(gpmod, n, D):
     """Option chain_split (gp/gp.go:228-230, the diagonal-block work of Factorize): the 256 x 256 diagonal block factored
@@ -533,7 +595,7 @@ def test_diagonal_block_in_two_halves_matches_the_256_block_kernel(gpmod, n, D):
     simil, noise = kernel.Scaled(kernel.Matern32), kernel.UniformNoise
     x = np.log([1.2, 0.5, 0.2])
     out = {}
-    for split in (0, 1):
+    for split in (0, 1, 2):
         g = gpmod.GP(D, simil, noise, X=X, Y=y)
         g.set_option("chain_split", split)
         lml = g.Observe(x)
@@ -545,24 +607,14 @@ def test_diagonal_block_in_two_halves_matches_the_256_block_kernel(gpmod, n, D):
         mu_a, sg_a = g.Produce(Z)
         out[split] = (lml, grad, mu, sg, g.Alpha.copy(), g.L.copy(), cl, cg, list(cs), mu_a, sg_a)
         g.close()
-    a, b = out[0], out[1]
-    assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
-    np.testing.assert_allclose(b[1], a[1], rtol=1e-9, atol=1e-9 * np.abs(a[1]).max())
-    np.testing.assert_allclose(b[2], a[2], rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(b[3], a[3], rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(b[4], a[4], rtol=1e-9, atol=1e-9 * np.abs(a[4]).max())
-    np.testing.assert_allclose(b[5], a[5], rtol=0, atol=1e-12 * np.abs(a[5]).max())
-    np.testing.assert_allclose(b[6], a[6], rtol=1e-12)
-    np.testing.assert_allclose(b[7], a[7], rtol=1e-9, atol=1e-9 * np.abs(a[7]).max())
-    assert a[8] == b[8] == [0, 0, 0]
-    np.testing.assert_allclose(b[9], a[9], rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(b[10], a[10], rtol=1e-8, atol=1e-11)
+    for other in (1, 2):
+        _same_results(out[0], out[other])
     # the failing pivot is reported from whichever half meets it (gp/gp.go:228-230): inputs so far apart that K = I in
     # floating point, the last one duplicated -- the last pivot is exactly 1 - 1 = 0 on every path
     for m in (2, 130, 200, 300):
         Xd = 100.0 * np.arange(m, dtype=float)[:, None]
         Xd[-1] = Xd[-2]
-        for split in (0, 1):
+        for split in (0, 1, 2):
             g = gpmod.GP(1, kernel.Normal, kernel.ConstantNoise(0.0), ThetaSimil=[1.0])
             g.set_option("chain_split", split)
             with pytest.raises(gpmod.FactorizeError) as ei:

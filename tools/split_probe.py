@@ -13,7 +13,7 @@ for N in Ns:
     x = np.log([1.0, np.sqrt(D / 6.0), 0.1])
     g = G.GP(D, kernel.Scaled(kernel.Normal), kernel.UniformNoise, X=X, Y=y)
     res = {}
-    for split in (0, 1, 0, 1):
+    for split in (0, 1, 2, 0, 1, 2):
         g.set_option("chain_split", split)
         g.set_option("eager", 1)
         lml = g.Observe(x); g.Gradient()
