@@ -92,6 +92,7 @@ HOOK_SYMBOLS = [
      [ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_uint64), _dp]),
     ("gogp_test_dgemm_nt", ctypes.c_int,
      [ctypes.c_int, _i64, _i64, _i64, ctypes.c_double, _dp, _dp, ctypes.c_double, _dp]),
+    ("gogp_test_valu_cost", ctypes.c_int, [ctypes.c_int, _dp]),
     ("gogp_test_panel128", ctypes.c_int,
      [ctypes.c_int, _dp, _dp, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), _dp]),
     # per-rank replay of the sharded sweep (tools/sharded_replay.py): a transport that reads recorded panels

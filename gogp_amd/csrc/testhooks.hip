@@ -265,6 +265,68 @@ extern "C" int gogp_test_diag256(int device, const double *A, double *Lout, doub
   return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
 }
 
+// ---- instruction costs of the pivot chain (pivot16.h): cycles (s_memtime) per instruction of one wave alone on its SIMD,
+// for chains of dependent and runs of independent fp64 operations.  out[0..7]: dependent v_fma_f64, independent v_fma_f64,
+// dependent v_mov_b64_dpp row_newbcast, independent v_mov_b64_dpp, dependent v_rsq_f64, independent v_rsq_f64,
+// dependent v_mul_f64, dpp -> fma -> dpp -> fma dependent pairs (per pair).
+__global__ __launch_bounds__(64) void valu_cost_kernel(double *out, double seed) {
+  double x = seed + 1e-9 * threadIdx.x, y = 1.0000001, z = 0.9999999;
+  double a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+  unsigned long long t[9];
+#define GOGP_T(k) t[k] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define REP8(X) X X X X X X X X
+#define REP64(X) REP8(REP8(X))
+  GOGP_T(0);
+  asm volatile(REP64("v_fma_f64 %0, %0, %1, %2\n\t") : "+v"(a0) : "v"(y), "v"(z));
+  GOGP_T(1);
+  asm volatile(REP8("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
+                    "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9\n\t")
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y), "v"(z));
+  GOGP_T(2);
+  asm volatile(REP64("s_nop 1\n\tv_mov_b64_dpp %0, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t") : "+v"(a0));
+  GOGP_T(3);
+  asm volatile(REP8("v_mov_b64_dpp %0, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %1, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %2, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %3, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %4, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %5, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %6, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b64_dpp %7, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t")
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+  GOGP_T(4);
+  asm volatile(REP64("v_rsq_f64 %0, %0\n\t") : "+v"(a0));
+  GOGP_T(5);
+  asm volatile(REP8("v_rsq_f64 %0, %8\n\tv_rsq_f64 %1, %8\n\tv_rsq_f64 %2, %8\n\tv_rsq_f64 %3, %8\n\t"
+                    "v_rsq_f64 %4, %8\n\tv_rsq_f64 %5, %8\n\tv_rsq_f64 %6, %8\n\tv_rsq_f64 %7, %8\n\t")
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+  GOGP_T(6);
+  asm volatile(REP64("v_mul_f64 %0, %0, %1\n\t") : "+v"(a1) : "v"(y));
+  GOGP_T(7);
+  asm volatile(REP64("s_nop 1\n\tv_mov_b64_dpp %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_fma_f64 %0, %1, %2, %0\n\t")
+               : "+v"(a2), "+v"(a3) : "v"(y));
+  GOGP_T(8);
+#undef GOGP_T
+#undef REP8
+#undef REP64
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) out[k] = (double)(t[k + 1] - t[k]) / 64.0;
+  out[8 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+extern "C" int gogp_test_valu_cost(int device, double *out8) {
+  if (!out8) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  double *d = nullptr;
+  if (hipMalloc(&d, (8 + 64) * sizeof(double)) != hipSuccess) return GOGP_ENOMEM;
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(valu_cost_kernel, dim3(1), dim3(64), 0, 0, d, 1.5);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out8, d, 8 * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
 // Diagnostic: one 128-column chain step (panel128.hip) on a (128 + rows_below) x 128 panel given on the host (row-major,
 // ld = 128; the diagonal block's lower triangle is used): the factor of the diagonal block and the solved rows, 72
 // s_memtime stamps of the diagnostic build, and the HIP-event time of `reps` launches of the product build.

@@ -45,6 +45,11 @@ int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,
 int gogp_test_diag256(int device, const double *A, double *Lout, double *Dinv,
                       unsigned long long *stamps, double *elapsed_us);
 
+/* Cycles per instruction (s_memtime) of one wave alone on its SIMD, the operations of the pivot chain (pivot16.h):
+ * out8[0..7] = dependent v_fma_f64, independent v_fma_f64, dependent v_mov_b64_dpp row_newbcast, independent v_mov_b64_dpp,
+ * dependent v_rsq_f64, independent v_rsq_f64, dependent v_mul_f64, one dependent (dpp, fma) pair. */
+int gogp_test_valu_cost(int device, double *out8);
+
 /* Diagnostic hook for one 128-column step of the Cholesky chain (panel128.hip): a (128 + rows_below) x 128 panel given on
  * the host (row-major, ld 128, lower triangle of the diagonal block used; rows_below a multiple of 64); returns the factor
  * of the diagonal block with the solved rows under it (same layout), 72 in-kernel s_memtime stamps of a diagnostic build
