@@ -266,6 +266,7 @@ extern "C" void gogp_destroy(gogp_handle *h) {
   free_cand_buffers(h);
   (void)hipFree(h->scalars);
   (void)hipFree(h->dscr);
+  (void)hipFree(h->D64);
   (void)hipFree(h->info);
   (void)hipFree(h->gout);
   (void)hipFree(h->devP);
@@ -477,6 +478,27 @@ static int ensure_y(gogp_handle *h) {
   return GOGP_OK;
 }
 
+// fp32 path: the strip of diagonal blocks accumulated in fp64 (diagsyrk.hip)
+static int ensure_d64(gogp_handle *h) {
+  if (h->D64 && h->cap_d64 >= h->npad) return GOGP_OK;
+  (void)hipFree(h->D64);
+  h->D64 = nullptr;
+  h->cap_d64 = 0;
+  const int64_t cap = std::max(h->npad, h->cap_npad);
+  HIPCHK(h, hipMalloc(&h->D64, (size_t)cap * PANEL * sizeof(double)));
+  h->cap_d64 = cap;
+  return GOGP_OK;
+}
+// D64 blocks first .. first + nblk - 1 -= their rows of L[:, k0 : k0 + K] times themselves (float operands, fp64 sums)
+static void d64_update(gogp_handle *h, hipStream_t s, const float *L, int64_t ld, int64_t k0, int64_t K, int first, int nblk) {
+  launch_diag_syrk_f64(s, L + (int64_t)first * PANEL * ld + k0, ld, K, h->D64 + (size_t)first * PANEL * PANEL, nblk);
+}
+static void d64_update(gogp_handle *, hipStream_t, const double *, int64_t, int64_t, int64_t, int, int) {}
+static void d64_init(gogp_handle *h, hipStream_t s, const float *A, int64_t ld, int first, int nblk) {
+  launch_widen_diag_blocks(s, A + (int64_t)first * PANEL * (ld + 1), ld, h->D64 + (size_t)first * PANEL * PANEL, nblk);
+}
+static void d64_init(gogp_handle *, hipStream_t, const double *, int64_t, int, int) {}
+
 // What the scalars of one factorisation say (row of the pinned staging block: [0] 2 sum log L_ii,
 // [1] z^T z, [3], [4] min / max L_ii, [5] fp64 log-determinant of the fp32 path, [6] y^T alpha of the
 // refined alpha, [8] first failing pivot + 1).
@@ -540,7 +562,10 @@ static void diag_block(gogp_handle *h, hipStream_t sp, const double *A, int64_t 
 static void diag_block(gogp_handle *h, hipStream_t sp, const float *A, int64_t ld, float *L, int64_t ldl,
                        float *Dp, int64_t c0) {
   double *A64 = h->dscr, *L64 = h->dscr + PANEL * PANEL, *D64 = h->dscr + 2 * PANEL * PANEL;
-  launch_convert_block(sp, A, ld, A64, PANEL, PANEL, PANEL);
+  if (h->d64_active)  // option "diag_fp64": the block as the fp64 strip accumulated it (diagsyrk.hip), not the float one
+    A64 = h->D64 + (size_t)(c0 / PANEL) * PANEL * PANEL;
+  else
+    launch_convert_block(sp, A, ld, A64, PANEL, PANEL, PANEL);
   launch_diag256(sp, A64, PANEL, L64, PANEL, D64, c0, h->n, h->info);
   launch_convert_block(sp, L64, PANEL, L, ldl, PANEL, PANEL);
   launch_convert_block(sp, D64, PANEL, Dp, PANEL, PANEL, PANEL);
@@ -920,6 +945,16 @@ static int factorize_t(gogp_handle *h, bool eager) {
     launch_gram_lower_split(sp, s, h->devP, h->D, h->dX, h->n, npad, reinterpret_cast<T *>(h->bufA), ld,
                             (int64_t)superpanel_width(h, (int)(npad / PANEL), 0) * PANEL);
   }
+  // fp32 path, option "diag_fp64": the diagonal blocks leave the float matrix here -- widened once, every later
+  // contribution summed in fp64 (diagsyrk.hip); the first super-panel's on the chain stream, the rest behind the build
+  h->d64_active = sizeof(T) == 4 && h->diag_fp64 != 0;
+  if (h->d64_active) {
+    rc = ensure_d64(h);
+    if (rc != GOGP_OK) return rc;
+    const int np = (int)(npad / PANEL), w0 = std::min(np, superpanel_width(h, np, 0));
+    d64_init(h, sp, reinterpret_cast<const T *>(h->bufA), ld, 0, w0);
+    if (np > w0) d64_init(h, s, reinterpret_cast<const T *>(h->bufA), ld, w0, np - w0);
+  }
   (void)gogp::rec_event_record(ev(h, EV_GRAM), s);  // the whole lower triangle is written (s after sp's part
                                             // is NOT implied: consumers of columns < 512 are on sp)
   if (eager) {
@@ -980,6 +1015,8 @@ static int factorize_t(gogp_handle *h, bool eager) {
         launch_gemm_nt(sp, GEMM_RECT, mt2, 2, PANEL, 1.0, A + c2 * ld + c0, ld, Dp, PANEL, 0.0,
                         L + c2 * ld + c0, ld, pf, &gtri);
       }
+      // fp32 path: the rest of the super-panel's diagonal blocks take this panel's contribution in fp64
+      if (h->d64_active && c2 < CE) d64_update(h, sp, L, ld, c0, PANEL, p + 1, (int)((CE - c2) / PANEL));
       // Updates inside the super-panel, grouped like a binary counter: after panel q the
       // next g = lowbit(q+1) block columns receive the LAST g panels at once (K = 256 g), each
       // column from its own diagonal block down (the blocks above belong to R of the fused
@@ -1032,11 +1069,14 @@ static int factorize_t(gogp_handle *h, bool eager) {
       gch.prio = chain_prio_of(h);
       launch_gemm_nt(sp, GEMM_TRAP, mtE, ntn, Kw, -1.0, L + CE * ld + C0, ld, L + CE * ld + C0, ld,
                       1.0, A + CE * ld + CE, ld, pf, &gch);
+      // fp32 path: ... and so do the next super-panel's diagonal blocks, in fp64 (diagsyrk.hip)
+      if (h->d64_active) d64_update(h, sp, L, ld, C0, Kw, (int)(CE / PANEL), ntn / 2);
       // the rest of the trailing matrix, lower tiles only (main stream)
       if (mtE > ntn) {
         const int64_t C3 = CE + (int64_t)ntn * TILE;
         launch_gemm_nt(s, GEMM_LOWER, mtE - ntn, mtE - ntn, Kw, -1.0, L + C3 * ld + C0, ld,
                         L + C3 * ld + C0, ld, 1.0, A + C3 * ld + C3, ld, pf);
+        if (h->d64_active) d64_update(h, s, L, ld, C0, Kw, (int)(C3 / PANEL), (mtE - ntn) / 2);
       }
       (void)gogp::rec_event_record(ev(h, EV_BASE + 4 * P0 + 1), s);  // bulk update of super-panel P0 done
     }
@@ -2472,6 +2512,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
     h->use_graph = (int)value;
     h->graph_failed = false;
     drop_cand_graph(h);
+    return GOGP_OK;
+  }
+  if (strcmp(name, "diag_fp64") == 0) {  // fp32 path: the diagonal blocks' trailing updates accumulated in fp64 (diagsyrk.hip)
+    if (value < 0 || value > 1) return fail(h, GOGP_EARG, "diag_fp64 must be 0 or 1");
+    h->diag_fp64 = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "refine_steps") == 0) {

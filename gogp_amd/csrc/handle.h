@@ -30,6 +30,10 @@ struct gogp_handle {
   double *z = nullptr, *w = nullptr, *alpha = nullptr;
   double *scalars = nullptr;  // 8 doubles
   double *dscr = nullptr;     // fp32 path: fp64 scratch of the diagonal-block kernel (3 x 256 x 256)
+  double *D64 = nullptr;      // fp32 path: the diagonal blocks accumulated in fp64 (diagsyrk.hip), npad / 256 blocks of 256 x 256
+  int64_t cap_d64 = 0;        // ... allocated for this npad
+  int diag_fp64 = 1;          // option "diag_fp64": 1 (default) the fp32 path's pivots come from that strip, 0 from the float matrix
+  bool d64_active = false;    // set by the factorisation in progress
   int prec = 64;              // 64: fp64 throughout; 32: N x N matrices and O(N^3) products in fp32
   size_t esz() const { return prec == 32 ? sizeof(float) : sizeof(double); }
   int refine_steps = 1;       // fp32 path: iterative-refinement steps of alpha against the fp64 K

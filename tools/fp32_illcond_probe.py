@@ -8,13 +8,13 @@ from gogp_amd import gp as G, kernel
 from oracle.oracle import FastOracle
 d = np.load(os.path.join(ROOT, "tests", "golden", "fp32_illcond_matern32.npz"))
 X, y, x = d["X"], d["y"], d["x"]
-simil, noise = kernel.Scaled(kernel.Matern32), kernel.UniformNoise
+simil, noise = kernel.Scaled(kernel.Matern32), kernel.ScaledNoise(0.01)  # tests/cases.py: "matern32"
 o = FastOracle(2, simil, noise)
 o.set_data(X, y)
 lml_o, grad_o = o.Observe(x), o.Gradient()
 scale = np.abs(grad_o).max()
 print("theta", np.exp(x), "oracle lml %.9f grad %s" % (lml_o, grad_o))
-for prec, opts in ((32, {}), (32, {"refine_steps": 3}), (32, {"eager": 0}), (32, {"trace_fp64": 0}), (64, {"gradient_precision": 32}), (64, {})):
+for prec, opts in ((32, {}), (32, {"diag_fp64": 0}), (32, {"refine_steps": 3}), (32, {"eager": 0}), (32, {"trace_fp64": 0}), (64, {"gradient_precision": 32}), (64, {})):
     g = G.GP(2, simil, noise, X=X, Y=y, precision=prec)
     for k, v in opts.items():
         g.set_option(k, v)
