@@ -811,10 +811,16 @@ static void mixed_superstep(gogp_handle *h, int P0, int nsub, int prevP0, int ne
 // 2: the chain per 128 columns is ONE launch (panel128.hip: every workgroup factors the diagonal 128-block redundantly
 // and forward-substitutes its own 64 panel rows on the way: no block inverse and no solve launch on the chain); the
 // 256 x 256 block inverses are formed off the chain from the finished factor (dinv_blocks below).
-static inline int chain_split_of(const gogp_handle *h, bool eager) {
+// Above that size, beside the inverse, the choice CAN be made super-panel by super-panel: form 2 once at most `chain_tail`
+// rows (option) remain below the super-panel's first column, where the bulk updates are small and a launch has few
+// workgroups to repeat the diagonal block in.  Measured (tools/tail_probe.py, N = 16384, alternating on one box): tail 0 /
+// 2048 / 4096 / 6144 / 8192 rows: 71.0 / 71.2 / 72.2 / 72.2 / 72.8 ms; N = 32768: 542.4 / - / 543.5 / - / 545.3 -- the
+// evaluation's tail is not waiting for the Cholesky chain (the inverse's chain runs beside it and fills what it leaves):
+// default 0, off.
+static inline int chain_split_of(const gogp_handle *h, bool eager, int64_t C0) {
   if (h->dist || h->prec != 64) return 0;
   if (h->chain_split >= 0) return h->chain_split;
-  return (h->npad <= 8192 || !eager) ? 2 : 0;
+  return (h->npad <= 8192 || !eager || h->npad - C0 <= h->chain_tail) ? 2 : 0;
 }
 static void split_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, double *Dp, int64_t ld, int64_t c0,
                         int64_t npad, GemmProfile *pf) {
@@ -971,7 +977,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
   T *Dinv = reinterpret_cast<T *>(h->Dinv);
   GemmProfile *pf = &h->prof;
   const int npanel = (int)(npad / PANEL);
-  const int split = std::is_same<T, double>::value ? chain_split_of(h, eager) : 0;
+
   if (!h->batch_mode) h->tinv_valid = false;  // Produce assembles T^-1 of the new factor on its first call
   if (sizeof(T) == 4) HIPCHK(h, hipMemsetAsync(h->scalars + 5, 0, sizeof(double), sp));  // fp64 logdet
   // working copy of y for the forward substitution (runs on the panel stream)
@@ -990,6 +996,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
     nsub = superpanel_width(h, npanel, P0);
     const int next_nsub = (P0 + nsub < npanel) ? superpanel_width(h, npanel, P0 + nsub) : 0;
     const int64_t C0 = (int64_t)P0 * PANEL, CE = C0 + (int64_t)nsub * PANEL;
+    const int split = std::is_same<T, double>::value ? chain_split_of(h, eager, C0) : 0;  // the form of this super-panel's chain
     for (int q = 0; q < nsub; ++q) {
       const int p = P0 + q;
       const int64_t c0 = (int64_t)p * PANEL, c2 = c0 + PANEL;
@@ -2488,6 +2495,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "chain_prio") == 0) {  // -1: by size, 0: off, 1: the chains' skinny launches, 2: all their launches
     if (value < -1 || value > 2) return fail(h, GOGP_EARG, "chain_prio must be -1..2");
     h->chain_prio = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "chain_tail") == 0) {  // chain_split = -1 above npad = 8192 beside the inverse: form 2 once this many rows remain
+    if (value < 0 || value > (1 << 20)) return fail(h, GOGP_EARG, "chain_tail must be 0..2^20");
+    h->chain_tail = value;
     return GOGP_OK;
   }
   if (strcmp(name, "chain_split") == 0) {  // -1: by size, 0: 256-block kernel, 1: two 128-halves + products on the tile kernel

@@ -397,7 +397,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          diagonal 128-block and forward-substitutes every panel row on the way (panel128.hip), the
  *                          block inverses are formed off the chain from the finished factor; -1: 2 where the
  *                          evaluation is latency-bound (N <= 8192) or no fp64 inverse runs beside the factorisation
- *                          (Absorb, eager = 0), 0 otherwise                                          (default -1)
+ *                          (Absorb, eager = 0); above that, beside the inverse, 0 -- and 2 for the super-panels with at
+ *                          most "chain_tail" rows left                                                (default -1)
+ *   "chain_tail"   0..2^20 rows (see chain_split; measured slower at N = 16384 and 32768)            (default 0)
  *   "produce_small_max" 0..64   gogp_produce with up to this many test points: ONE persistent launch that reads the
  *                          factor once (trsm_small.hip) instead of the tile-kernel chain; 0: never  (default 64)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
