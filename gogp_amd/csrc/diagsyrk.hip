@@ -22,16 +22,18 @@ constexpr int DS_T = 64;    // tile
 constexpr int DS_KC = 16;   // k per staged chunk
 constexpr int DS_LD = 18;   // LDS leading dimension: fragment reads of 16 rows x 2 k hit 64 distinct banks
 
-// blockIdx.x: lower 64 x 64 tile (ti >= tj) of the 256-block, blockIdx.y: block b -- rows Lrows + b * 256 * ld, K columns;
-// D64 + b * 65536 (leading dimension 256) -= rows_ti rows_tj^T
+// blockIdx.x: lower 64 x 64 tile (ti >= tj) of the BS x BS block, blockIdx.y: block b -- its BS rows of K float columns start at
+// Lrows + b * row_stride; D64 + b * BS^2 (leading dimension BS) -= rows_ti rows_tj^T.  BS = 256: the single-GPU path's
+// diagonal blocks (row_stride = 256 ld); BS = 512: the diagonal tiles of a sharded evaluation, whose rows of the panel are
+// the rank's own nb x nb tiles of it (dist2d.hip: row_stride = tiles between two diagonal tiles of this rank).
 __global__ __launch_bounds__(256, 2) void diag_syrk_kernel(const float *__restrict__ Lrows, long ld, long K,
-                                                         double *__restrict__ D64) {
+                                                         double *__restrict__ D64, long row_stride, int BS) {
   __shared__ __attribute__((aligned(16))) double As[2][DS_T * DS_LD], Bs[2][DS_T * DS_LD];
   int t = blockIdx.x, ti = 0;
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   const int tj = t - ti * (ti + 1) / 2;
-  const float *base = Lrows + (long)blockIdx.y * PANEL * ld;
-  double *D = D64 + (long)blockIdx.y * PANEL * PANEL;
+  const float *base = Lrows + (long)blockIdx.y * row_stride;
+  double *D = D64 + (long)blockIdx.y * BS * BS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void diag_syrk_kernel(const float *__restri
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      acc[c][v] = D[(long)(ti * DS_T + 16 * w + fk + 4 * v) * PANEL + tj * DS_T + 16 * c + fr];
+      acc[c][v] = D[(long)(ti * DS_T + 16 * w + fk + 4 * v) * BS + tj * DS_T + 16 * c + fr];
   float4 ra = *reinterpret_cast<const float4 *>(pa), rb = *reinterpret_cast<const float4 *>(pb);
   const int so = sr * DS_LD + sk;
   const long nch = K / DS_KC;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void diag_syrk_kernel(const float *__restri
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      D[(long)(ti * DS_T + 16 * w + fk + 4 * v) * PANEL + tj * DS_T + 16 * c + fr] = acc[c][v];
+      D[(long)(ti * DS_T + 16 * w + fk + 4 * v) * BS + tj * DS_T + 16 * c + fr] = acc[c][v];
 }
 
 // D64 block b <- the float block at A + b * 256 * (ld + 1), widened (lower triangle used later; all of it copied)
@@ -91,7 +93,16 @@ __global__ __launch_bounds__(256) void widen_diag_blocks_kernel(const float *__r
 
 void launch_diag_syrk_f64(hipStream_t s, const float *Lrows, int64_t ld, int64_t K, double *D64, int nblocks) {
   if (nblocks <= 0 || K <= 0) return;
-  GOGP_KLAUNCH(diag_syrk_kernel, dim3(10, (unsigned)nblocks), dim3(256), 0, s, Lrows, (long)ld, (long)K, D64);
+  GOGP_KLAUNCH(diag_syrk_kernel, dim3(10, (unsigned)nblocks), dim3(256), 0, s, Lrows, (long)ld, (long)K, D64,
+               (long)PANEL * (long)ld, (int)PANEL);
+}
+
+void launch_diag_syrk_f64_tiles(hipStream_t s, const float *Lrows, int64_t ld, int64_t K, double *D64, int nblocks,
+                                int64_t row_stride, int bs) {
+  if (nblocks <= 0 || K <= 0) return;
+  const int nt = bs / DS_T;
+  GOGP_KLAUNCH(diag_syrk_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)nblocks), dim3(256), 0, s, Lrows, (long)ld,
+               (long)K, D64, (long)row_stride, bs);
 }
 
 void launch_widen_diag_blocks(hipStream_t s, const float *A, int64_t ld, double *D64, int nblocks) {

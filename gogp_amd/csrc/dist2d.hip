@@ -83,6 +83,12 @@ struct Dist2D {
   int64_t cap_npad = 0;
   int64_t bytes = 0;
   double *t64 = nullptr;    // fp32 evaluation: fp64 images of one diagonal tile (A, L, inverse: 3 x nb x nb)
+  // fp32 evaluation, option "diag_fp64" (diagsyrk.hip): this rank's tiles of the GLOBAL diagonal kept in fp64 -- every
+  // panel's contribution summed in fp64 from the float panel tiles.  They are the local tile rows dq_first, dq_first +
+  // dq_step, ... (dq_count of them; none when the rank's grid row and column never meet on the diagonal).
+  double *d64 = nullptr;
+  int dq_first = 0, dq_step = 1, dq_count = 0;
+  bool d64_on = false;      // set by the evaluation in progress
   int ldA() const { return nloc * nb; }
   // The matrix buffers above (A, Lch, Ych, Dinv, the panel rings, pack) hold T = double or -- on a
   // handle with precision 32 -- float elements; typed views:
@@ -127,7 +133,7 @@ static inline void wait(gogp_handle *h, hipStream_t s, size_t i) { (void)hipStre
 
 static void dist_free_n(Dist2D *d) {
   for (double *p : {d->A, d->Lch, d->Ych, d->Dinv, d->Yrow[0], d->Yrow[1], d->Ycol[0], d->Ycol[1], d->pack,
-                    d->yloc, d->rloc, d->red, d->ared, d->gpart, d->tpart})
+                    d->yloc, d->rloc, d->red, d->ared, d->gpart, d->tpart, d->d64})
     (void)hipFree(p);
   d->rloc = nullptr;
   for (int i = 0; i < LRING; ++i) {
@@ -135,7 +141,7 @@ static void dist_free_n(Dist2D *d) {
     (void)hipFree(d->Lcol[i]);
     d->Lrow[i] = d->Lcol[i] = nullptr;
   }
-  d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = d->tpart = nullptr;
+  d->A = d->Lch = d->Ych = d->Dinv = d->pack = d->yloc = d->red = d->ared = d->gpart = d->tpart = d->d64 = nullptr;
   for (int i = 0; i < 2; ++i) d->Yrow[i] = d->Ycol[i] = nullptr;
   d->cap_npad = 0;
   d->bytes = 0;
@@ -335,6 +341,18 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
   d->NB = (int)(npad / d->nb);
   d->mloc = d->NB / d->Pr;
   d->nloc = d->NB / d->Pc;
+  {
+    // this rank's tiles of the global diagonal: local tile row bi is global I = pr + Pr bi, mine iff I = pc (mod Pc);
+    // Pr | Pc, so: iff pc = pr (mod Pr) and bi = (pc - pr) / Pr (mod Pc / Pr)
+    const int qq = d->Pc / d->Pr;
+    d->dq_step = qq;
+    d->dq_first = 0;
+    d->dq_count = 0;
+    if ((d->pc - d->pr) % d->Pr == 0) {
+      d->dq_first = (((d->pc - d->pr) / d->Pr) % qq + qq) % qq;
+      if (d->mloc > d->dq_first) d->dq_count = (d->mloc - d->dq_first + qq - 1) / qq;
+    }
+  }
   if (npad > d->cap_npad) {
     // the unsharded N x N buffers are never allocated on a sharded handle
     for (double **p : {&h->dX, &h->dy, &h->bufA, &h->bufL, &h->bufY, &h->Dinv, &h->z, &h->w, &h->alpha,
@@ -376,6 +394,7 @@ int gogp_dist_ensure_n(gogp_handle *h, int64_t n) {
       HIPCHK(h, hipMalloc(&h->rpart, (size_t)REFINE_SLABS * npad * sizeof(double)));
       d->bytes += (int64_t)((size_t)(1 + REFINE_SLABS) * npad * sizeof(double));
     }
+    if (h->prec == 32 && d->dq_count > 0) DMALLOC(d->d64, (size_t)d->dq_count * nb2);  // (npad is the largest so far: so is dq_count)
     DMALLOC(d->red, (size_t)npad + 1 + d->nranks);
     DMALLOC(d->ared, (size_t)npad);
     DMALLOC(d->gpart, (size_t)grad_reduce_blocks_local((int64_t)mrows, (int64_t)ncols) * NACC);
@@ -449,7 +468,10 @@ static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d
   float *Lblk = d->lchunk<float>(bj_d) + (size_t)bi_d * nb2;
   float *Dv = d->mat<float>(d->Dinv) + (size_t)P * nb2;
   double *A64 = d->t64, *L64 = d->t64 + nb2, *D64 = d->t64 + 2 * nb2;
-  launch_convert_block(sp, Ablk, ldA, A64, nb, nb, nb);
+  if (d->d64_on)  // option "diag_fp64": the tile as its fp64 image accumulated it (diagsyrk.hip), not the float one
+    A64 = d->d64 + (size_t)((bi_d - d->dq_first) / d->dq_step) * nb2;
+  else
+    launch_convert_block(sp, Ablk, ldA, A64, nb, nb, nb);
   diag_tile64(h, d, sp, A64, nb, L64, D64, (int64_t)P * nb);
   launch_convert_block(sp, L64, nb, Lblk, nb, nb, nb);
   launch_convert_block(sp, D64, nb, Dv, nb, nb, nb);
@@ -464,6 +486,18 @@ static void diag_tile(gogp_handle *h, Dist2D *d, hipStream_t sp, int P, int bi_d
       return r_;                               \
     }                                          \
   } while (0)
+
+static void widen_tile(hipStream_t s, const float *src, int lds_, double *dst, int nb) {
+  launch_convert_block(s, src, lds_, dst, nb, nb, nb);
+}
+static void widen_tile(hipStream_t, const double *, int, double *, int) {}
+// my fp64 diagonal tiles t0 .. t0 + cnt - 1 -= their panel tiles (local tile rows dq_first + t dq_step of Lrow) times themselves
+static void d64_tiles_update(Dist2D *d, hipStream_t s, const float *Lrow, int t0, int cnt) {
+  const size_t nb2 = (size_t)d->nb * d->nb;
+  launch_diag_syrk_f64_tiles(s, Lrow + (size_t)(d->dq_first + t0 * d->dq_step) * nb2, d->nb, d->nb, d->d64 + (size_t)t0 * nb2,
+                             cnt, (int64_t)d->dq_step * (int64_t)nb2, d->nb);
+}
+static void d64_tiles_update(Dist2D *, hipStream_t, const double *, int, int) {}
 
 // ---- one sharded evaluation: Gram + Cholesky + triangular inverse (+ K^-1) -------------------
 template <class T>
@@ -495,6 +529,15 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
   // the strictly upper blocks are zero-filled (R)
   launch_gram_local(s, h->devP, h->D, h->dX, h->n, (int64_t)mloc * nb, (int64_t)nloc * nb, d->map(), A,
                     ldA);
+  // fp32 evaluation, option "diag_fp64": my tiles of the global diagonal leave the float matrix here (widened once; every
+  // later contribution is summed in fp64 from the float panel tiles: diagsyrk.hip, api.hip does the same per 256-block)
+  d->d64_on = sizeof(T) == 4 && h->diag_fp64 != 0 && d->dq_count > 0 && d->d64;
+  if (sizeof(T) == 4 && h->diag_fp64 != 0 && d->dq_count == 0) d->d64_on = false;
+  if (d->d64_on)
+    for (int t = 0; t < d->dq_count; ++t) {
+      const int bi = d->dq_first + t * d->dq_step, bj = (pr + Pr * bi - pc) / Pc;
+      widen_tile(s, A + (size_t)bi * nb * ldA + (size_t)bj * nb, ldA, d->d64 + (size_t)t * nb2, nb);
+    }
   rec(h, EV_GRAM, s);
   for (hipStream_t qs : {sp, st, s2, sc}) wait(h, qs, EV_GRAM);
 
@@ -611,8 +654,21 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
                         ldA, pf, &gg);
         cst = bj0 + 1;
       }
+      // fp32 evaluation: my diagonal tiles below block row P take this panel's contribution in fp64 -- the one the next
+      // step factors on the chain stream, the others with the bulk update
+      int dt0 = 0, dtn = 0;   // first of my diagonal tiles with global index > P, and whether it is tile P + 1
+      if (d->d64_on) {
+        dt0 = bi0 <= d->dq_first ? 0 : (bi0 - d->dq_first + d->dq_step - 1) / d->dq_step;
+        if (dt0 < d->dq_count && pr + Pr * (d->dq_first + dt0 * d->dq_step) == P + 1) {
+          wait(h, sp, E(P, EL));
+          if (P >= 1) wait(h, sp, E(P - 1, EUPD));
+          d64_tiles_update(d, sp, Lrow, dt0, 1);
+          dtn = 1;
+        }
+      }
       rec(h, E(P, ELA), sp);
       wait(h, s, E(P, EL));
+      if (d->d64_on && dt0 + dtn < d->dq_count) d64_tiles_update(d, s, Lrow, dt0 + dtn, d->dq_count - dt0 - dtn);
       if (bi0 < mloc && cst < nloc) {
         gg.cblk0 = cst;
         launch_gemm_nt(s, GEMM_RECT, (mloc - bi0) * tpb, (nloc - cst) * tpb, nb, -1.0,

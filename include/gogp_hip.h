@@ -386,9 +386,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          off the float K^-1 (1.9e-4 measured), beyond the reference's own 1e-4 (gp_test.go:170,248)
  *   "trace_fp64"   1 | 0   float K^-1 (precision = 32, gradient_precision = 32): tr(alpha alpha^T - K^-1) summed in
  *                          fp64 from Y and the output-scale component from its closed form          (default 1)
- *   "diag_fp64"    1 | 0   fp32 path (single GPU): the 256 x 256 diagonal blocks' trailing updates are summed in fp64
- *                          from the float panels (diagsyrk.hip) and the fp64 diagonal-block kernel factors THAT block;
- *                          0: it widens the float matrix's block (rounds 2-4)                        (default 1)
+ *   "diag_fp64"    1 | 0   fp32 path (single GPU and float shards): the diagonal blocks' / tiles' trailing updates are
+ *                          summed in fp64 from the float panels (diagsyrk.hip) and the fp64 diagonal-block kernel
+ *                          factors THAT image; 0: it widens the float matrix's block (rounds 2-4)    (default 1)
  *   "krag"         1 | 0   the triangular inverse's updates skip the zero triangle of a super-panel of Y (default 1)
  *   "chain_split"  -1 | 0 | 1 | 2   fp64, the factorisation's dependency chain per 256-panel: 0 one workgroup factors and
  *                          inverts the 256 x 256 diagonal block, the panel solve is a K = 256 product with that inverse;

@@ -267,6 +267,47 @@ def expected_exchange_bytes(npad, grid, nb=512):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid", [(1, 1), (1, 2), (2, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
+def test_sharded_fp32_diagonal_tiles_in_fp64(grid):
+    """Float shards on the ill-conditioned golden case (tests/golden/fp32_illcond_matern32.npz; Matern-3/2, N = 1721,
+    D = 2): every rank keeps its tiles of the GLOBAL diagonal in fp64 and sums the panels' contributions to them in fp64
+    (diagsyrk.hip, option diag_fp64 -- the float trailing updates bias the factor's diagonal), so the
+    gradient stays inside the 1e-4 the reference checks its own gradient to (gp_test.go:170,248) as on one GPU; with the
+    option off the noise component is outside it."""
+    from gogp_amd import kernel
+    from gogp_amd.sharded import ShardedGP
+    from oracle.oracle import FastOracle
+    import loopback
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp32_illcond_matern32.npz"))
+    X, y, x = d["X"], d["y"], d["x"]
+    simil, noise = kernel.Scaled(kernel.Matern32), kernel.ScaledNoise(0.01)
+    o = FastOracle(2, simil, noise)
+    o.set_data(X, y)
+    lml_o, grad_o = o.Observe(x), o.Gradient()
+    np.testing.assert_allclose(grad_o, d["grad_oracle"], rtol=1e-9)
+    scale = np.abs(grad_o).max()
+    world = grid[0] * grid[1]
+
+    def rank_fn(r, lb):
+        out = []
+        for on in (1, 0):
+            sh = ShardedGP(2, simil, noise, X=X, Y=y, device=0, precision=32, grid=grid, rank=r, world=world,
+                           exchange=lb.exchange, allreduce=lb.allreduce)
+            sh.set_option("diag_fp64", on)
+            out.append((sh.Observe(x), sh.Gradient()))
+            sh.close()
+        return out
+
+    outs, lb = loopback.run_ranks(world, rank_fn)
+    assert loopback.check_rendezvous(lb.log) is None
+    for (lml, grad), (lml0, grad0) in outs:
+        assert abs(lml - lml_o) <= 2e-6 * abs(lml_o)
+        err = np.abs(grad - grad_o) / scale
+        assert err.max() <= 1e-4, (grad, grad_o, err)
+        assert np.abs(grad0 - grad_o).max() / scale > 1e-4   # what the float diagonal tiles gave
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(1, 1), (1, 2), (2, 2), (2, 4)], ids=lambda g: "%dx%d" % g)
 def test_sharded_fp32_tiles_keep_the_accuracy_contract(grid):
     """precision = 32 on a sharded handle: float tiles, panels and exchanges, fp32 MFMA products;
     fp64 diagonal tiles, log-determinant, z / alpha sums and one refinement step of alpha against
