@@ -10,11 +10,11 @@ cp "$(newest "$O/stats_c2/*/*_kernel_stats.csv")" $P/r0${R:-4}_c2_kernel_stats.c
 cp "$(newest "$O/stats_c2k8/*/*_kernel_stats.csv")" $P/r0${R:-4}_c2_candidates8_kernel_stats.csv
 cp "$(newest "$O/stats_c5/*/*_kernel_stats.csv")" $P/r0${R:-4}_c5_fp32_n32768_kernel_stats.csv
 cp $O/pmc_summary_c3.txt $P/r0${R:-4}_pmc_summary_c3.txt
-cp $O/pmc_summary_c5.txt $P/r0${R:-4}_pmc_summary_c5_fp32_n16384.txt
+if [ "${R:-4}" -ge 5 ]; then cp $O/pmc_summary_c5.txt $P/r0${R:-4}_pmc_summary_c5.txt; else cp $O/pmc_summary_c5.txt $P/r0${R:-4}_pmc_summary_c5_fp32_n16384.txt; fi  # round 5: config 5's own N = 65536
 cp $O/roofline_c3.json $P/r0${R:-4}_c3_roofline.json
 cp $O/roofline_c2.json $P/r0${R:-4}_c2_roofline.json
 cp $O/roofline_c5_n32768.json $P/r0${R:-4}_c5_fp32_n32768_roofline.json
 cp $O/pmc_traffic.json $P/r0${R:-4}_pmc_traffic.json
-cp $O/gemm_bench.txt $P/r0${R:-4}_gemm_bench.txt
-for f in gemm_fixedcost graph_probe produce_probe mixed_probe; do [ -f $O/$f.txt ] && cp $O/$f.txt $P/r0${R:-4}_$f.txt; done
+[ -f $O/gemm_bench.txt ] && cp $O/gemm_bench.txt $P/r0${R:-4}_gemm_bench.txt
+for f in gemm_fixedcost graph_probe produce_probe mixed_probe produce_small_probe split_probe panel_probe valu_cost fp32_bias_probe; do [ -f $O/$f.txt ] && cp $O/$f.txt $P/r0${R:-4}_$f.txt; done
 ls -la $P | grep r0${R:-4}_
