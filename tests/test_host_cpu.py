@@ -173,8 +173,12 @@ def test_bench_reports_pmc_traffic_only_for_the_build_it_was_measured_on():
     assert why is None and e["bytes_per_launch"] == d["3"]["bytes_per_launch"]
     e, why = bench.pmc_traffic(3, "0123456789ab")
     assert e is None and "stale" in why and d["build"] in why
-    e, why = bench.pmc_traffic(4, d["build"])
+    e, why = bench.pmc_traffic(1, d["build"])   # round 5 measured configs 2-5 at their own sizes; config 1 has no pass
     assert e is None and "no PMC pass" in why
+    for c in ("2", "4", "5"):
+        if c in d:
+            e, why = bench.pmc_traffic(int(c), d["build"])
+            assert why is None and e["bytes_per_launch"] == d[c]["bytes_per_launch"]
     # the version string of the built library ends in a 12-digit hex build id
     from gogp_amd import _lib
     v = _lib.lib().gogp_version().decode()
@@ -231,7 +235,13 @@ def test_tracked_bench_line_carries_the_contract_fields():
     assert line["lml_rel_err_vs_oracle"] < 1e-6 and line["mu_rel_err_vs_oracle"] < 1e-6 and line["sigma_rel_err_vs_oracle"] < 1e-6
     p = line["produce"]
     assert p["m"] == 1024 and abs(p["roofline"]["frac"] - 16384.0 ** 2 * 1024 / (p["ms_per_call"] * 1e-3) / 78.6e12) < 1e-9
-    assert [q["m"] for q in p["m_sweep"]] == [1, 64, 8192]
+    ms = [q["m"] for q in p["m_sweep"]]
+    assert ms[0] == 1 and 64 in ms and ms[-1] == 8192
+    for q in p["m_sweep"]:   # few test points: one pass over the factor, priced against HBM (round 5); many: the fp64 roof
+        rq = q["roofline"]
+        assert rq["bound"] == ("hbm" if q["m"] <= 64 else "mfma")
+        if q["m"] <= 64:
+            assert abs(rq["frac"] - 8.0 * 16384.0 ** 2 / 2 / (q["ms_per_call"] * 1e-3) / 8e12) < 1e-9
     m = line["mixed_precision_gradient"]  # an option beside the value, never the value
     assert m["lml_identical_to_native"] is True and m["grad_rel_diff_vs_native"] < 1e-6
     assert m["evals_per_s"] > line["value"] and "not `value`" in m["note"]
