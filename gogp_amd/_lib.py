@@ -95,6 +95,7 @@ HOOK_SYMBOLS = [
     ("gogp_test_valu_cost", ctypes.c_int, [ctypes.c_int, _dp]),
     ("gogp_test_panel128", ctypes.c_int,
      [ctypes.c_int, _dp, _dp, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), _dp]),
+    ("gogp_test_panel128_slabs", ctypes.c_int, [ctypes.c_int, _dp, _dp, _i64, ctypes.c_int, ctypes.c_int, _dp]),
     # per-rank replay of the sharded sweep (tools/sharded_replay.py): a transport that reads recorded panels
     ("gogp_test_dist_init_replay", ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4),
 ]

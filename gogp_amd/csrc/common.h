@@ -244,6 +244,9 @@ void launch_diag_syrk_f64_tiles(hipStream_t s, const float *Lrows, int64_t ld, i
 // half 0 / 1 of the 256-block at A is factored and the rows_below (multiple of 64) rows under it are solved against it
 void launch_panel128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, int half, int64_t rows_below,
                      int64_t row0, int64_t nvalid, long long *info);
+// the same with the number of 64-row slabs per workgroup forced (0: by size); the result does not depend on it
+void launch_panel128_slabs(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, int half,
+                           int64_t rows_below, int64_t row0, int64_t nvalid, long long *info, int slabs);
 // dense inverses of nblk consecutive 256 x 256 diagonal blocks of a finished factor (block b at L + b * 256 * (ld + 1))
 void launch_dinv256_blocks(hipStream_t s, const double *L, int64_t ld, double *Dinv, int nblk);
 void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv);  // Dinv: ld 512

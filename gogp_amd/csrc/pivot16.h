@@ -39,11 +39,15 @@ struct Fill {
 // interleave (left alone it hoists every broadcast to the top: 267 VGPR spills, or sinks every update to the column that
 // needs it: a second dependent chain).
 // RINV: lane r of every row of 16 lanes also keeps 1/L_rr of ITS pivot row in `mine` (the 16 x 16 block inverses of
-// diag256.hip start from it).
-template <int J, bool RINV>
+// diag256.hip start from it).  SAVE: the column's two scaling factors -- rs after the first Newton step and the last
+// correction e -- go to sv[svs J], sv[svs J + 1]: with them SolveColumn below repeats the panel rows' arithmetic on OTHER
+// rows, operation for operation (panel128.hip: further slabs of rows per workgroup).  Branch-free: ONE lane is handed the
+// real table with svs = 2, every other lane a two-double scratch of its own with svs = 0 (a branch per column would cut
+// the pass into sixteen basic blocks and undo its schedule: 636 VGPR spills).
+template <int J, bool RINV, bool SAVE = false>
 struct PivotColumn {
   static __device__ __forceinline__ void run(double (&ad)[16], double (&ap)[16], double d, double lq, double pq, int &bad,
-                                             double &mine, int r) {
+                                             double &mine, int r, double *sv = nullptr, int svs = 0) {
     constexpr int n = J > 0 ? 15 - J : 0, c0 = J + 1;  // pending: columns J + 1 .. 15 of the update by column J - 1
 #define GOGP_CHUNK(k)                                                              \
   Fill<c0 + ((k) * n + 7) / 8, c0 + (((k) + 1) * n + 7) / 8>::run(ad, ap, lq, pq); \
@@ -69,6 +73,10 @@ struct PivotColumn {
     ad[J] = ld;
     ap[J] = lp;
     if (RINV) mine = (r == J) ? fma(rs, e, rs) : mine;
+    if (SAVE) {
+      sv[svs * J] = rs;
+      sv[svs * J + 1] = e;
+    }
     GOGP_CHUNK(6);
     if constexpr (J < 15) {
       const double b = bcast16<J + 1>(ld), bo = bcast16<J + 1>(ad[J + 1]);
@@ -77,9 +85,36 @@ struct PivotColumn {
       ad[J + 1] = fma(-ld, b, ad[J + 1]);
       ap[J + 1] = fma(-lp, b, ap[J + 1]);
       __builtin_amdgcn_sched_barrier(0);
-      PivotColumn<J + 1, RINV>::run(ad, ap, dn, ld, lp, bad, mine, r);
+      PivotColumn<J + 1, RINV, SAVE>::run(ad, ap, dn, ld, lp, bad, mine, r, sv, svs);
     }
 #undef GOGP_CHUNK
+  }
+};
+
+// The panel rows' half of PivotColumn on its own: rows ap against a pivot block that is ALREADY factored (ad: lane r of
+// every row of 16 lanes holds row r of the factor block) with the saved scalings sv -- the same multiplications and FMAs on
+// ap, in the same order per accumulator, as the pass that factored the block did on its own panel rows: the same bits.
+template <int J, int C>
+struct SolveFill {
+  static __device__ __forceinline__ void run(const double (&ad)[16], double (&ap)[16], double lp) {
+    if constexpr (C < 16) {
+      ap[C] = fma(-lp, bcast16<C>(ad[J]), ap[C]);
+      SolveFill<J, C + 1>::run(ad, ap, lp);
+    }
+  }
+};
+template <int J>
+struct SolveColumn {
+  static __device__ __forceinline__ void run(const double (&ad)[16], double (&ap)[16], const double *sv) {
+    const double rs = sv[2 * J], e = sv[2 * J + 1];
+    const double gp = ap[J] * rs;
+    const double lp = fma(gp, e, gp);
+    ap[J] = lp;
+    if constexpr (J < 15) {
+      SolveFill<J, J + 1>::run(ad, ap, lp);
+      __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists all 120 broadcasts to the top: 636 VGPR spills)
+      SolveColumn<J + 1>::run(ad, ap, sv);
+    }
   }
 };
 

@@ -377,6 +377,44 @@ extern "C" int gogp_test_panel128(int device, const double *A, double *Lout, int
   return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
 }
 
+// The product build of the chain step with the number of 64-row slabs per workgroup forced (panel128.hip: the result must
+// not depend on it), on a (128 + rows_below) x 128 panel given on the host; HIP-event time per launch over `reps` launches.
+extern "C" int gogp_test_panel128_slabs(int device, const double *A, double *Lout, int64_t rows_below, int slabs, int reps,
+                                        double *elapsed_us) {
+  if (!A || !Lout || rows_below < 0 || rows_below % 64 || slabs < 0 || slabs > 8 || reps <= 0) return GOGP_EARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOGP_EHIP;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return GOGP_EHIP;
+  const size_t rows = 128 + (size_t)rows_below, nb2 = rows * 256 * sizeof(double);
+  double *dA = nullptr, *dL = nullptr;
+  long long *dinfo = nullptr;
+  hipError_t e = hipMalloc(&dA, nb2);
+  if (e == hipSuccess) e = hipMalloc(&dL, nb2);
+  if (e == hipSuccess) e = hipMalloc(&dinfo, 8);
+  if (e == hipSuccess) e = hipMemset(dL, 0, nb2);
+  if (e == hipSuccess) e = hipMemset(dinfo, 0, 8);
+  if (e == hipSuccess) e = hipMemcpy2D(dA, 256 * sizeof(double), A, 128 * sizeof(double), 128 * sizeof(double), rows, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    gogp::launch_panel128_slabs(0, dA, 256, dL, 256, 0, rows_below, 0, (int64_t)rows, dinfo, slabs);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) gogp::launch_panel128_slabs(0, dA, 256, dL, 256, 0, rows_below, 0, (int64_t)rows, dinfo, slabs);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy2D(Lout, 128 * sizeof(double), dL, 256 * sizeof(double), 128 * sizeof(double), rows, hipMemcpyDeviceToHost);
+  if (elapsed_us) *elapsed_us = ms * 1e3 / reps;
+  (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dinfo);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return e == hipSuccess ? GOGP_OK : GOGP_EHIP;
+}
+
 // Benchmark hook for the tile kernel: times `reps` launches of one GEMM shape on
 // device-resident pseudo-random operands (lda = ldb = K, ldc = nt*128).
 extern "C" int gogp_bench_gemm(int device, int mode, int mt, int nt, int64_t K, int reps,

@@ -57,6 +57,11 @@ int gogp_test_valu_cost(int device, double *out8);
 int gogp_test_panel128(int device, const double *A, double *Lout, int64_t rows_below, int reps,
                        unsigned long long *stamps, double *elapsed_us);
 
+/* The product build of that step with the number of 64-row slabs per workgroup forced (0: by size): the factor and the
+ * solved rows (same layout) and the HIP-event time per launch.  The result must not depend on `slabs`. */
+int gogp_test_panel128_slabs(int device, const double *A, double *Lout, int64_t rows_below, int slabs, int reps,
+                             double *elapsed_us);
+
 /* Per-rank replay of a sharded evaluation (tools/sharded_replay.py): makes handle `h` (a
  * gogp_handle of the product library) rank `rank` of a prow x pcol grid ALONE on its GPU -- nothing is sent, a receive
  * zero-fills its buffer, an all-reduce is the identity.  Every launch of that rank's share of the sweep runs with its

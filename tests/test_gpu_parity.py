@@ -569,6 +569,34 @@ def test_chain_step_kernel_against_numpy(rows_below):
         np.testing.assert_allclose(L[128:], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("rows_below", [64, 192, 1024])
+def test_chain_step_result_does_not_depend_on_slabs_per_workgroup(rows_below):
+    """panel128.hip, multi-slab workgroups (launches with more workgroups than compute units: k candidates, tall panels): a
+    workgroup factors the diagonal block once and treats further slabs of 64 panel rows with the saved pivot scalings --
+    the same operations on every row as the one-slab form, so the bits must agree whatever the number of slabs; candidates
+    and single calls (gp/gp.go:228 behind both) stay bit-identical because of it."""
+    import ctypes
+    from gogp_amd import _lib
+    H = _lib.hooks()
+    rng = np.random.default_rng(rows_below + 7)
+    n = 128 + rows_below
+    B = rng.normal(size=(n, 150))
+    K = B @ B.T / 150 + 0.3 * np.eye(n)
+    A = np.ascontiguousarray(K[:, :128])
+    outs = []
+    for slabs in (1, 2, 3, 4):
+        L = np.zeros_like(A)
+        us = ctypes.c_double()
+        assert H.gogp_test_panel128_slabs(0, A.ctypes.data_as(_lib._dp), L.ctypes.data_as(_lib._dp), rows_below, slabs, 1,
+                                          ctypes.byref(us)) == 0
+        outs.append(L)
+    Ld = np.linalg.cholesky(K[:128, :128])
+    ref = np.linalg.solve(Ld, K[128:, :128].T).T
+    np.testing.assert_allclose(outs[0][128:], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    for L in outs[1:]:
+        np.testing.assert_array_equal(L, outs[0])
+
+
 def _same_results(a, b):
     assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
     np.testing.assert_allclose(b[1], a[1], rtol=1e-9, atol=1e-9 * np.abs(a[1]).max())

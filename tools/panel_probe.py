@@ -35,3 +35,13 @@ for rb in rows_list:
               (kb, (a - prev) * tick, (b - a) * tick, (c - b) * tick, (d - b) * tick, (e - b) * tick, (e - prev) * tick))
         prev = e
     print("   last pivot block stored at %.2f after entry" % ((s[4] - t0) * tick))
+# multi-slab workgroups (launches with more workgroups than compute units): time per launch against slabs per workgroup
+for rb in (4096, 16256, 31744):
+    n = 128 + rb
+    A = np.ascontiguousarray(rng.normal(size=(n, 128)) * 0.01)
+    A[:128] += np.eye(128) * 2.0
+    for slabs in (1, 2, 4):
+        L = np.zeros_like(A)
+        us = ctypes.c_double()
+        assert H.gogp_test_panel128_slabs(0, A.ctypes.data_as(_lib._dp), L.ctypes.data_as(_lib._dp), rb, slabs, 20, ctypes.byref(us)) == 0
+        print("rows_below %5d, %d slab(s) per workgroup (%d workgroups): %.2f us per launch" % (rb, slabs, -(-(rb // 64) // slabs), us.value))
