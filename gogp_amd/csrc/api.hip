@@ -848,10 +848,10 @@ static void fused_panel(gogp_handle *h, hipStream_t sp, double *A, double *L, in
   const int mt1 = (int)((npad - c1) / TILE);
   GemmGrid gch;
   gch.prio = chain_prio_of(h);
-  launch_panel128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 0, npad - c1, c0, h->n, h->info);
+  launch_panel128_slabs(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 0, npad - c1, c0, h->n, h->info, h->chain_slabs);
   launch_gemm_nt(sp, GEMM_RECT, mt1, 1, TILE, -1.0, L + c1 * ld + c0, ld, L + c1 * ld + c0, ld, 1.0, A + c1 * ld + c1, ld,
                  pf, &gch);
-  launch_panel128(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 1, npad - c2, c0, h->n, h->info);
+  launch_panel128_slabs(sp, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, 1, npad - c2, c0, h->n, h->info, h->chain_slabs);
 }
 static void fused_panel(gogp_handle *, hipStream_t, float *, float *, int64_t, int64_t, int64_t, GemmProfile *) {}
 static void dinv_blocks(hipStream_t s, const double *L, double *Dinv, int64_t ld, int P0, int nsub) {
@@ -1996,6 +1996,7 @@ static void produce_solve_t(gogp_handle *h, hipStream_t s, int64_t m, int64_t mp
   if (use_tinv && ensure_tinv(h) != GOGP_OK) {  // no memory for T^-1: panel-by-panel substitution, and no stale message
     use_tinv = false;
     h->err.clear();
+    (void)hipGetLastError();  // ... and no sticky allocation error for the final check of the call
   }
   const bool assemble = use_tinv && !(h->tinv_valid && h->tinv_sig == tinv_signature(h));
   // Right behind an eager Observe the streams of the triangular inverse (st, s2, sk) still hold two thirds of an
@@ -2495,6 +2496,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "chain_prio") == 0) {  // -1: by size, 0: off, 1: the chains' skinny launches, 2: all their launches
     if (value < -1 || value > 2) return fail(h, GOGP_EARG, "chain_prio must be -1..2");
     h->chain_prio = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "chain_slabs") == 0) {  // chain_split = 2: 64-row slabs per workgroup of the chain step; 0: by size (the result does not depend on it)
+    if (value < 0 || value > 8) return fail(h, GOGP_EARG, "chain_slabs must be 0..8");
+    h->chain_slabs = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "chain_tail") == 0) {  // chain_split = -1 above npad = 8192 beside the inverse: form 2 once this many rows remain

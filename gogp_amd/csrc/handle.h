@@ -65,7 +65,7 @@ struct gogp_handle {
   bool batch_mode = false;      // a batched evaluation is being enqueued (also with k = 1)
   // option "graph": the launch sequence of a batched evaluation captured once into a hipGraph and
   // replayed (the parameters change in pinned host memory only)
-  int use_graph = 1;            // 1: linear graph from stream capture (N <= 1024; the default), 2: explicitly built DAG (graphrec.h), 0: none
+  int use_graph = 1;            // 1: linear graph from stream capture (N <= 1024; the default), 2: explicitly built DAG (graphrec.h), 3: the same recorder as one chain in enqueue order (diagnostics), 0: none
   bool graph_failed = false;    // the runtime refused the explicit graph once: stream path from then on
   int graph_nodes = 0;          // nodes of the graph in use (diagnostics)
   std::string graph_note;
@@ -93,6 +93,7 @@ struct gogp_handle {
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int64_t chain_tail = 0;      // chain_split = -1, large N beside the inverse: panel128 for the super-panels with at most this many rows left (0: none)
+  int chain_slabs = 0;         // chain_split = 2: slabs of 64 panel rows per workgroup (panel128.hip); 0: by the launch's size
   int chain_split = -1;        // 1: the diagonal block in two 128-halves, their products on the tile kernel; 2: panel128.hip (api.hip; -1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)
   // T^-1 (lower, row-major) of the diagonal block of every super-panel of the factor: rows C0.. of an npad x tinv_ld
