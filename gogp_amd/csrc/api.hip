@@ -2073,11 +2073,26 @@ static int produce_small(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad,
     HIPCHK(h, hipMalloc(&h->small_ws, need));
     h->small_ws_bytes = need;
   }
+  const bool f32 = h->prec == 32;  // float factor / inverses / Kstar: widened as the kernel reads them, sums in fp64
   {
     AuxTimer tm(h, GOGP_PROF_CROSS, s);
-    launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, h->KsT, ld);  // gp/gp.go:322-332
+    if (f32)
+      launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, reinterpret_cast<float *>(h->KsT), ld);
+    else
+      launch_cross(s, h->devP, h->D, h->dX, h->n, npad, h->dZ, m, mpad, h->KsT, ld);  // gp/gp.go:322-332
   }
-  launch_rownorm_dot(s, h->KsT, ld, h->alpha, npad, m, dmu, nullptr);  // mean = Kstar^T alpha (gp/gp.go:335)
+  // mean = Kstar^T alpha (gp/gp.go:335)
+  if (f32)
+    launch_rownorm_dot(s, reinterpret_cast<const float *>(h->KsT), ld, h->alpha, npad, m, dmu, nullptr);
+  else
+    launch_rownorm_dot(s, h->KsT, ld, h->alpha, npad, m, dmu, nullptr);
+  auto solve = [&](hipStream_t q, int j0, int cnt, void *ws, unsigned **tm) {
+    if (f32)
+      launch_trsm_small(q, reinterpret_cast<const float *>(h->bufL), ld, reinterpret_cast<const float *>(h->Dinv),
+                        reinterpret_cast<const float *>(h->KsT), ld, npad, j0, cnt, ws, dq, tm);
+    else
+      launch_trsm_small(q, h->bufL, ld, h->Dinv, h->KsT, ld, npad, j0, cnt, ws, dq, tm);
+  };
   unsigned *tmo = nullptr, *tmo2 = nullptr;
   unsigned *htmo = reinterpret_cast<unsigned *>(h->hscal + 10);
   htmo[0] = htmo[1] = 0;
@@ -2089,10 +2104,10 @@ static int produce_small(gogp_handle *h, hipStream_t s, int64_t m, int64_t mpad,
     // the second 32 columns on a second stream, beside the first (both launches read the same factor at the same
     // time: what one pulls into the Infinity Cache the other finds there)
     if (s2nd != s) order(h, ev0 + 1, s, s2nd);
-    launch_trsm_small(s2nd, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 32, (int)m - 32, (char *)h->small_ws + one, dq, &tmo2);
+    solve(s2nd, 32, (int)m - 32, (char *)h->small_ws + one, &tmo2);
     HIPCHK(h, hipMemcpyAsync(htmo + 1, tmo2, sizeof(unsigned), hipMemcpyDeviceToHost, s2nd));
   }
-  launch_trsm_small(s, h->bufL, ld, h->Dinv, h->KsT, ld, npad, 0, m1, h->small_ws, dq, &tmo);
+  solve(s, 0, m1, h->small_ws, &tmo);
   HIPCHK(h, hipMemcpyAsync(htmo, tmo, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   if (m > 32 && s2nd != s) order(h, ev0 + PRODUCE_GROUPS + 1, s2nd, s);
   return GOGP_OK;
@@ -2127,7 +2142,9 @@ extern "C" int gogp_produce(gogp_handle *h, const double *Z, int64_t m, double *
   }
   rc = ensure_alpha(h);
   if (rc != GOGP_OK) return rc;
-  const bool small = h->prec == 64 && m <= h->produce_small_max;
+  // (float matrices: up to 16 test points -- measured at N = 65536: M = 1 / 16 / 64 in 4.5 / 5.0 / 11.2 ms against 7.5 on
+  // the float tile-kernel chain, N = 16384: 0.92 / 0.94 / 1.53 against 1.07: the float chain is twice as fast as the fp64 one)
+  const bool small = m <= h->produce_small_max && (h->prec == 64 || m <= 16);
   if (small) {
     rc = produce_small(h, s, m, mpad, dmu, dq);
     if (rc != GOGP_OK) return rc;

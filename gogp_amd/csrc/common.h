@@ -320,6 +320,8 @@ void launch_trace_from_y(hipStream_t s, const float *Y, int64_t ld, int64_t n, i
 size_t trsm_small_workspace_bytes(int64_t npad);
 void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double *Dinv, const double *KsT, int64_t ldk,
                        int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev);
+void launch_trsm_small(hipStream_t s, const float *L, int64_t ld, const float *Dinv, const float *KsT, int64_t ldk,
+                       int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev);  // fp32 path
 void launch_fill(hipStream_t s, double *p, int64_t count, double v);
 void launch_axpy(hipStream_t s, double *a, const double *b, int64_t count);  // a += b
 void launch_dot(hipStream_t s, const double *a, const double *b, int64_t n, double *out);  // out[0] = a.b

@@ -42,11 +42,14 @@ constexpr int TS_RT = 64;                  // rows per workgroup (4 waves x 16)
 constexpr int TS_WPB = PANEL / TS_RT;      // workgroups per 256-block
 constexpr unsigned TS_SPIN_MAX = 1u << 22;  // polls (~1 us each with the s_sleep) before a workgroup gives up
 
+// TL: element type of the matrices (the factor, its block inverses, the right-hand sides): double, or float on the fp32
+// path -- widened as they arrive in registers; the substitution itself (v, w, every sum) is fp64 either way
+template <class TL>
 struct TsArgs {
-  const double *L;
+  const TL *L;
   long ld;
-  const double *Dinv;  // nb blocks of 256 x 256 (lower, upper zero)
-  const double *KsT;   // right-hand sides, [j][i] (row j = test point), leading dimension ldk
+  const TL *Dinv;  // nb blocks of 256 x 256 (lower, upper zero)
+  const TL *KsT;   // right-hand sides, [j][i] (row j = test point), leading dimension ldk
   long ldk;
   int j0;              // first right-hand side of this launch
   double *Vk;          // solution, pair-interleaved: element (row k, rhs j) at ((k >> 1) * MP + j) * 2 + (k & 1)
@@ -86,8 +89,8 @@ __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) {
 // by a straight 16-B copy); MC = 1, 2, 4, 8 (NT = 1): only the MC live columns travel ([k][MC]; one row per thread of
 // the staging copy), the other columns of the LDS operand are zeros written once -- one test point hands 2 KB from
 // block to block instead of 32 KB, and every hand-off is on the substitution's critical path.
-template <int NT, int MC>
-__global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
+template <int NT, int MC, class TL>
+__global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs<TL> g) {
   constexpr int MP = 16 * NT;
   constexpr bool FULL = MC == MP;
   static_assert(FULL || (NT == 1 && (MC == 1 || MC == 2 || MC == 4 || MC == 8)), "compact exchange: NT = 1, MC in {1, 2, 4, 8}");
@@ -107,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   // is never read again is a register hipcc hands to other code, which then waits for the load still in flight into it
 
   // ---- operand ring: chunk q -> this lane's eight 16-B pieces --------------------------------------
-  const double *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
-  const double *Drow = g.Dinv + (long)B * PANEL * PANEL + (long)(sub * TS_RT + 16 * w + fr) * PANEL + 2 * fk;
+  const TL *Lrow = g.L + (r0 + fr) * g.ld + 2 * fk;
+  const TL *Drow = g.Dinv + (long)B * PANEL * PANEL + (long)(sub * TS_RT + 16 * w + fr) * PANEL + 2 * fk;
   // ---- accumulators: acc = sum_j L v_j - b  (so w = -acc); loaded BEFORE the ring's first requests (vector loads
   // return in order: every later wait for a ring slot then covers them, see trsv_granule_kernel) ----------------
   f64x4 acc[NT];
@@ -116,12 +119,20 @@ __global__ __launch_bounds__(256, 2) void trsm_small_kernel(TsArgs g) {
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      acc[nt][v] = -g.KsT[(long)(g.j0 + fr + 16 * nt) * g.ldk + r0 + fk + 4 * v];
+      acc[nt][v] = -(double)g.KsT[(long)(g.j0 + fr + 16 * nt) * g.ldk + r0 + fk + 4 * v];
   f64x2 ar[4][8];
   auto issue = [&](int q, f64x2(&slot)[8]) {
-    const double *p = (q < 4 * B) ? Lrow + (long)q * 64 : Drow + (long)(q - 4 * B) * 64;
+    const TL *p = (q < 4 * B) ? Lrow + (long)q * 64 : Drow + (long)(q - 4 * B) * 64;
+    if constexpr (sizeof(TL) == 8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) slot[i] = *reinterpret_cast<const f64x2 *>(p + 8 * i);
+      for (int i = 0; i < 8; ++i) slot[i] = *reinterpret_cast<const f64x2 *>(p + 8 * i);
+    } else {  // float matrices: the same two elements per lane and piece, 8 bytes, widened on arrival
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float2 v = *reinterpret_cast<const float2 *>(p + 8 * i);
+        slot[i] = (f64x2){(double)v.x, (double)v.y};
+      }
+    }
   };
   // (chunk indices are clamped to the last one instead of guarded: a conditional load makes every ring register a
   // phi of "old or new" and hipcc then keeps both -- 137 VGPR spills in the one-right-hand-side kernel; the repeated
@@ -532,12 +543,9 @@ size_t trsm_small_workspace_bytes(int64_t npad) {
 // V = L^-1 Kstar for the right-hand sides j0 .. j0 + cnt - 1 (rows of KsT, cnt <= 32); dq[j] = |V_j|^2 for those j.
 // ws: trsm_small_workspace_bytes(npad) bytes of this launch's own.  *tmo_dev: device word that is non-zero afterwards
 // if a workgroup gave up waiting (the caller copies it back and reports GOGP_EHIP).
-void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double *Dinv, const double *KsT, int64_t ldk,
-                       int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev) {
-  if (j0 == 0 && cnt == 1) {
-    launch_trsv_granule(s, L, ld, Dinv, KsT, npad, ws, dq, tmo_dev);
-    return;
-  }
+template <class TL>
+static void launch_trsm_small_t(hipStream_t s, const TL *L, int64_t ld, const TL *Dinv, const TL *KsT, int64_t ldk,
+                                int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev) {
   const int nb = (int)(npad / PANEL), nwg = (int)(npad / TS_RT);
   char *p = (char *)ws;
   unsigned *flags = (unsigned *)p;  // [cnt | done | tmo ...]: one block at the start of the allocation, zeroed per call
@@ -545,7 +553,7 @@ void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double 
   p += (fbytes + 255) / 256 * 256;
   (void)rec_memset_async(flags, 0, fbytes, s);
   if (tmo_dev) *tmo_dev = flags + 2 * nb;
-  TsArgs g;
+  TsArgs<TL> g;
   g.L = L;
   g.ld = (long)ld;
   g.Dinv = Dinv;
@@ -568,12 +576,12 @@ void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double 
     if (lds > 64 * 1024 - 1) {                                                                                         \
       static bool raised = false; /* 64 KB + 16 B of dynamic LDS: above the default limit */                           \
       if (!raised) {                                                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_small_kernel<NTV, MCV>),                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_small_kernel<NTV, MCV, TL>),                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         raised = true;                                                                                                 \
       }                                                                                                                \
     }                                                                                                                  \
-    GOGP_KLAUNCH((trsm_small_kernel<NTV, MCV>), dim3(nwg), dim3(256), lds, s, g);                                      \
+    GOGP_KLAUNCH((trsm_small_kernel<NTV, MCV, TL>), dim3(nwg), dim3(256), lds, s, g);                                        \
     GOGP_KLAUNCH(trsm_small_finish_kernel, dim3(1), dim3(64), 0, s, (const double *)g.sqpart, nwg, 16 * (NTV), m_end, \
                  j0, dq);                                                                                              \
   } while (0)
@@ -584,6 +592,21 @@ void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double 
   else if (cnt <= 16) GOGP_TS(1, 16);
   else GOGP_TS(2, 32);
 #undef GOGP_TS
+}
+
+void launch_trsm_small(hipStream_t s, const double *L, int64_t ld, const double *Dinv, const double *KsT, int64_t ldk,
+                       int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev) {
+  if (j0 == 0 && cnt == 1) {  // one right-hand side: the data-tagged granule kernel
+    launch_trsv_granule(s, L, ld, Dinv, KsT, npad, ws, dq, tmo_dev);
+    return;
+  }
+  launch_trsm_small_t<double>(s, L, ld, Dinv, KsT, ldk, npad, j0, cnt, ws, dq, tmo_dev);
+}
+// fp32 path: float factor, block inverses and right-hand sides; the counter kernel for every M (one right-hand side too:
+// the granule kernel's LDS-DMA images are laid out for doubles)
+void launch_trsm_small(hipStream_t s, const float *L, int64_t ld, const float *Dinv, const float *KsT, int64_t ldk,
+                       int64_t npad, int j0, int cnt, void *ws, double *dq, unsigned **tmo_dev) {
+  launch_trsm_small_t<float>(s, L, ld, Dinv, KsT, ldk, npad, j0, cnt, ws, dq, tmo_dev);
 }
 
 }  // namespace gogp

@@ -403,8 +403,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          not depend on it; 0: one while the launch has at most a workgroup per compute unit, up to 4
  *                          beyond (measured at N = 16384: 1 / 2 / 4 slabs 30.1 / 32.0 / 35.4 ms Observe only) (default 0)
  *   "chain_tail"   0..2^20 rows (see chain_split; measured slower at N = 16384 and 32768)            (default 0)
- *   "produce_small_max" 0..64   gogp_produce with up to this many test points: ONE persistent launch that reads the
- *                          factor once (trsm_small.hip) instead of the tile-kernel chain; 0: never  (default 64)
+ *   "produce_small_max" 0..64   gogp_produce with up to this many test points (fp32 path: up to 16 of them): ONE
+ *                          persistent launch that reads the factor once (trsm_small.hip; float factors are widened in
+ *                          registers, the sums are fp64) instead of the tile-kernel chain; 0: never  (default 64)
  * No reference counterpart (gp.GP.Parallel, gp/gp.go:30-31, only switches goroutines on). */
 int gogp_set_option(gogp_handle *h, const char *name, int64_t value);
 

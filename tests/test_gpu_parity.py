@@ -1065,6 +1065,36 @@ def test_fp32_path_accuracy_contract(gpmod, shape):
     g8.close()
 
 
+@pytest.mark.parametrize("m", [1, 7, 16, 40])
+def test_fp32_produce_for_few_test_points(gpmod, m):
+    """gp/gp.go:322-357 on the fp32 path with M <= 16 test points (above: the float tile-kernel chain, which the last case
+    checks against itself): the one-pass persistent substitution (trsm_small.hip)
+    reads the FLOAT factor and block inverses, widens them in registers and sums in fp64 -- inside the fp32 contract
+    against the oracle (mu 1e-3, sigma 2e-4 of their largest values) and no worse than the float tile-kernel chain it
+    replaces (option produce_small_max = 0)."""
+    from gogp_amd import configs
+    from oracle.oracle import FastOracle
+    n = 2500
+    wl = configs.workload(5, n)
+    X, y = wl.inputs()
+    Z = wl.test_points(m)
+    x = wl.log_theta(0)
+    o = FastOracle(wl.D, wl.simil, wl.noise)
+    o.set_data(X, y)
+    o.Observe(x)
+    mu_o, sg_o = o.Produce(Z)
+    g = gpmod.GP(wl.D, wl.simil, wl.noise, X=X, Y=y, precision=32)
+    g.Observe(x)
+    mu, sg = g.Produce(Z)
+    g.set_option("produce_small_max", 0)
+    mu_c, sg_c = g.Produce(Z)
+    g.close()
+    e_mu, e_sg = np.abs(mu - mu_o).max() / np.abs(mu_o).max(), np.abs(sg - sg_o).max() / np.abs(sg_o).max()
+    c_mu, c_sg = np.abs(mu_c - mu_o).max() / np.abs(mu_o).max(), np.abs(sg_c - sg_o).max() / np.abs(sg_o).max()
+    assert e_mu <= 1e-3 and e_sg <= 2e-4, (e_mu, e_sg)
+    assert e_mu <= 2.0 * c_mu + 1e-6 and e_sg <= 2.0 * c_sg + 1e-6, (e_mu, c_mu, e_sg, c_sg)
+
+
 def test_fp32_gradient_ill_conditioned_case(gpmod, golden_dir):
     """The case round 3's randomised stress run found (tools/stress.py 360 7: Matern-3/2, N = 1721, D = 2, data kept
     in tests/golden/fp32_illcond_matern32.npz with the oracle's gradient and what the fp32 path returned then): LML
