@@ -871,7 +871,7 @@ def main():
                 g.profile_enable(False)
                 # algorithmic work of the solve (gp/gp.go:337-342 as ONE triangular solve): N^2 M flop
                 alg = float(N) * N * m
-                if m <= 64 and prec == 64:
+                if m <= (64 if prec == 64 else 16):  # (float factors: the one-pass substitution up to 16 test points)
                     # few test points: ONE persistent launch that reads the factor once (trsm_small.hip) -- bound by
                     # the pass over the lower triangle, 8 N^2 / 2 bytes (bytes of the HBM-bound sub-steps)
                     tri = esz * float(N) * N / 2.0
