@@ -1211,7 +1211,76 @@ static int factorize_t(gogp_handle *h, bool eager) {
   return fr.rc;
 }
 
+// ---- option "tiny" (default on): N <= 128 observations, the whole factorisation in ONE launch (diag256.hip: tiny_eval_kernel)
+// The reference's own case studies have 20 .. 200 observations (tutorial/data/*.csv); the general sweep is then a chain of
+// ~15 dependent launches (0.34 ms per Observe at N = 64, 30 us of it arithmetic).  Everything the later calls read is left
+// where the general path leaves it -- L, the block inverse, z, alpha, K^-1 (Observe) -- so Gradient, Produce, the factor
+// export and the lazy inverse after Absorb run unchanged; only Y = L^-T is not formed (nobody needs it once K^-1 exists).
+static inline bool tiny_ok(const gogp_handle *h) {
+  return h->tiny && !h->dist && h->prec == 64 && h->npad == PANEL && h->n <= TILE && !mixed_gradient(h);
+}
+static int tiny_factorize(gogp_handle *h, bool eager) {
+  hipStream_t s = h->s;
+  for (bool *pend : {&h->trtri_pending, &h->kinv_pending}) {
+    if (*pend) {  // a previous (general-path) evaluation left its inverse running: it reads L / Dinv and writes bufA
+      (void)gogp::rec_stream_wait(s, ev(h, pend == &h->trtri_pending ? EV_TRTRI : EV_KINV));
+      *pend = false;
+    }
+  }
+  if (h->kinv_c1 > 0 && !h->have_kinv) (void)gogp::rec_stream_wait(s, ev(h, EV_KINV));
+  h->factored = h->have_alpha = h->have_kinv = h->grad_valid = false;
+  h->alpha_pending = false;
+  h->trtri_done = false;
+  h->ydone_valid = false;
+  h->notpd = -1;
+  h->kinv_c1 = 0;
+  h->d64_active = false;
+  int rc = gogp_upload_params(h);
+  if (rc != GOGP_OK) return rc;
+  // whatever the chain / substitution streams still hold from a previous general-path call (the backward substitution of
+  // an Absorb reads L and Dinv) comes first
+  // (not inside a candidates call: its previous call joined every stream into the main one, and a captured sequence may
+  // not wait for work outside the capture)
+  if (h->lookahead && !h->batch_mode) {
+    order(h, EV_ENTRY, h->sp, s);
+    order(h, EV_W, h->sl, s);
+  }
+  if (!h->batch_mode) h->tinv_valid = false;
+  HIPCHK(h, cand_memset(h, h->info, sizeof(long long), s));
+  launch_tiny_eval(s, h->devP, h->dX, h->dy, h->n, h->bufA, h->bufL, h->Dinv, h->z, h->alpha, h->info, eager);
+  launch_lml_scalars(s, h->bufL, h->npad, h->z, nullptr, nullptr, h->n, h->scalars);
+  (void)gogp::rec_event_record(ev(h, EV_ALPHA), s);
+  HIPCHK(h, cand_d2h(h, h->hscal, h->scalars, 7 * sizeof(double), s));
+  HIPCHK(h, cand_d2h(h, h->hscal + 8, h->info, sizeof(long long), s));
+  h->alpha_pending = true;
+  if (h->batch_mode) {  // the caller synchronises and judges every candidate from its own row of hscal
+    h->factored = true;
+    h->have_alpha = true;
+    h->have_kinv = eager;
+    return GOGP_OK;
+  }
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  const FactorResult fr = judge_scalars(h, h->hscal, false, false);
+  if (fr.rc == GOGP_ENOTPD) {
+    h->alpha_pending = false;
+    h->tinv_valid = h->tinv_pending = false;
+    h->notpd = fr.notpd;
+    h->err = fr.msg;
+    return GOGP_ENOTPD;
+  }
+  h->lml = fr.lml;
+  h->yta = fr.yta;
+  h->factored = true;
+  h->have_alpha = true;
+  h->have_kinv = eager;
+  h->cond_lb = fr.cond_lb;
+  if (fr.rc == GOGP_ECOND) h->err = fr.msg;
+  return fr.rc;
+}
+
 static int factorize(gogp_handle *h, bool eager) {
+  if (tiny_ok(h)) return tiny_factorize(h, eager && h->lookahead);
   return h->prec == 32 ? factorize_t<float>(h, eager) : factorize_t<double>(h, eager);
 }
 
@@ -1719,7 +1788,7 @@ extern "C" int gogp_observe_gradient_candidates(gogp_handle *h, int k, const dou
       HIPCHK(h, gogp::rec_memcpy_async((char *)h->devP + (size_t)c * h->cand_stride, h->cand_hostP + c,
                                        sizeof(DevParams), hipMemcpyHostToDevice, h->s));
     const bool f32 = h->prec == 32;
-    int r = f32 ? factorize_t<float>(h, true) : factorize_t<double>(h, true);
+    int r = tiny_ok(h) ? tiny_factorize(h, true) : (f32 ? factorize_t<float>(h, true) : factorize_t<double>(h, true));
     if (r != GOGP_OK) return r;
     r = f32 ? compute_kinv_t<float>(h) : compute_kinv_t<double>(h);
     if (r != GOGP_OK) return r;
@@ -2513,6 +2582,11 @@ extern "C" int gogp_set_option(gogp_handle *h, const char *name, int64_t value) 
   if (strcmp(name, "chain_prio") == 0) {  // -1: by size, 0: off, 1: the chains' skinny launches, 2: all their launches
     if (value < -1 || value > 2) return fail(h, GOGP_EARG, "chain_prio must be -1..2");
     h->chain_prio = (int)value;
+    return GOGP_OK;
+  }
+  if (strcmp(name, "tiny") == 0) {  // N <= 128: the whole factorisation in one launch (diag256.hip: tiny_eval_kernel); 0: the general sweep
+    if (value < 0 || value > 1) return fail(h, GOGP_EARG, "tiny must be 0 or 1");
+    h->tiny = (int)value;
     return GOGP_OK;
   }
   if (strcmp(name, "chain_slabs") == 0) {  // chain_split = 2: 64-row slabs per workgroup of the chain step; 0: by size (the result does not depend on it)

@@ -247,6 +247,10 @@ void launch_panel128(hipStream_t s, const double *A, int64_t ld, double *Lout, i
 // the same with the number of 64-row slabs per workgroup forced (0: by size); the result does not depend on it
 void launch_panel128_slabs(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, int half,
                            int64_t rows_below, int64_t row0, int64_t nvalid, long long *info, int slabs);
+// diag256.hip: a whole evaluation of n <= 128 observations in one launch (npad = 256): Gram matrix, factor, block inverse, z,
+// alpha and (want_kinv) K^-1, left where the general path leaves them (A: K^-1 lower, L, Dinv: leading dimension 256)
+void launch_tiny_eval(hipStream_t s, const DevParams *P, const double *X, const double *y, int64_t n, double *A, double *L,
+                      double *Dinv, double *z, double *alpha, long long *info, bool want_kinv);
 // dense inverses of nblk consecutive 256 x 256 diagonal blocks of a finished factor (block b at L + b * 256 * (ld + 1))
 void launch_dinv256_blocks(hipStream_t s, const double *L, int64_t ld, double *Dinv, int nblk);
 void launch_diag256_inv_only_ld512(hipStream_t s, const double *L, int64_t ld, double *Dinv);  // Dinv: ld 512

@@ -38,6 +38,7 @@
 // 2 k hit 64 distinct banks), G = 2304 doubles: the eight 16x16 inverses during the factor /
 // inverse phases, the double-buffered B chunks during the products.
 #include "common.h"
+#include "kern_eval.h"
 #include "pivot16.h"
 
 // The test-hook library compiles this file a second time into its own namespace
@@ -696,6 +697,139 @@ __global__ __launch_bounds__(NT) void dinv256_blocks_kernel(const double *__rest
   diag256_body<false, false, 256>(S, G, rinv_s, L + b * 256 * (ld + 1), ld, nullptr, 0L, Dinv + b * 65536L, 0L, 0L, nullptr,
                                   nullptr);
 }
+
+// ---- tutorial-sized evaluations: N <= 128 observations in ONE workgroup, ONE launch ---------------------------------------
+// The reference's own case studies fit 20 ... 200 observations (tutorial/data/*.csv; BASELINE configs[0]: N = 64).  At that
+// size the general sweep is fifteen dependent launches of a few microseconds each (kernel trace at N = 64: 0.34 ms per
+// Observe, of which the arithmetic is 30 us).  Here workgroup 0 does gp/gp.go:109-236 in one go -- the Gram matrix of
+// the n <= 128 observations into LDS (kern_eval.h: simil_value; identity padding as everywhere), its Cholesky factor
+// (potrf128_lds), X = L^-1 (invert128_lds), z = X y, alpha = X^T z and, for Observe, K^-1 = X^T X on the matrix cores --
+// and writes L, the 256 x 256 block inverse, z, alpha and K^-1 where the general path leaves them; workgroups 1..3 fill
+// the constant quadrants of the padded 256-blocks meanwhile.  The log-determinant, the gradient reduction, Produce etc.
+// are the general path's kernels on these buffers.  Candidate batching as everywhere (blockIdx.z).
+__global__ __launch_bounds__(NT) void tiny_eval_kernel(const DevParams *__restrict__ Pp, const double *__restrict__ X,
+                                                        const double *__restrict__ y, long n, double *__restrict__ A,
+                                                        double *__restrict__ Lout, double *__restrict__ Dinv,
+                                                        double *__restrict__ z, double *__restrict__ alpha,
+                                                        long long *info, int want_kinv, long bstride) {
+  const DevParams &P = *gogp::cand(Pp, bstride);
+  A = gogp::cand(A, bstride);
+  Lout = gogp::cand(Lout, bstride);
+  Dinv = gogp::cand(Dinv, bstride);
+  z = gogp::cand(z, bstride);
+  alpha = gogp::cand(alpha, bstride);
+  info = gogp::cand(info, bstride);
+  const int tid = threadIdx.x;
+  if (blockIdx.x != 0) {
+    // the constant quadrants of the factor's and the inverse's padded 256-blocks: 1: top right, 2: bottom left (zeros),
+    // 3: bottom right (identity: the padding rows' own factor)
+    const int q = blockIdx.x, r0 = (q >= 2) ? 128 : 0, c0 = (q & 1) ? 128 : 0;
+    for (int idx = tid; idx < 128 * 64; idx += NT) {
+      const int i = idx >> 6, cc = (idx & 63) * 2;
+      const f64x2 v = {(q == 3 && cc == i) ? 1.0 : 0.0, (q == 3 && cc + 1 == i) ? 1.0 : 0.0};
+      *reinterpret_cast<f64x2 *>(Lout + (long)(r0 + i) * 256 + c0 + cc) = v;
+      *reinterpret_cast<f64x2 *>(Dinv + (long)(r0 + i) * 256 + c0 + cc) = v;
+      // ... and of K^-1's (the input-gradient kernel mirrors and reads the whole padded block)
+      if (want_kinv) *reinterpret_cast<f64x2 *>(A + (long)(r0 + i) * 256 + c0 + cc) = v;
+    }
+    if (q == 3)
+      for (int i = tid; i < 128; i += NT) z[128 + i] = alpha[128 + i] = 0.0;
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) double S[128 * SLD];
+  __shared__ __attribute__((aligned(16))) double G[GSIZE];
+  __shared__ double rinv_s[8 * 16];
+  __shared__ double ys[128], zs[128];
+  const int D = P.ndim;
+  // ---- the Gram matrix, lower triangle, into S (gp/gp.go:109-156; rows / columns >= n: identity) ------------------------
+  for (int idx = tid; idx < 128 * 128; idx += NT) {
+    const int i = idx >> 7, j = idx & 127;
+    double k = 0.0;
+    if (j <= i) {
+      if (i < n) {
+        const double *xi = X + (long)i * D, *xj = X + (long)j * D;
+        k = simil_value(P, [&](int d) { return xi[d]; }, [&](int d) { return xj[d]; });
+        if (i == j) k += P.noise_var;
+      } else {
+        k = (i == j) ? 1.0 : 0.0;
+      }
+    }
+    S[i * SLD + j] = k;
+  }
+  if (tid < 128) ys[tid] = tid < n ? y[tid] : 0.0;
+  __syncthreads();
+  potrf128_lds(S, G, rinv_s, tid, 0, n, info);
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
+    const int i = idx >> 6, cc = (idx & 63) * 2;
+    *reinterpret_cast<f64x2 *>(Lout + (long)i * 256 + cc) = *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+  }
+  __syncthreads();
+  invert128_lds(S, G, tid);  // S = X = L^-1 (lower)
+  for (int idx = tid; idx < 128 * 64; idx += NT) {
+    const int i = idx >> 6, cc = (idx & 63) * 2;
+    *reinterpret_cast<f64x2 *>(Dinv + (long)i * 256 + cc) = *reinterpret_cast<const f64x2 *>(S + i * SLD + cc);
+  }
+  // ---- z = X y, alpha = X^T z (gp/gp.go:232-236): row tid / 4, a quarter of the sum each, added in a fixed order -------
+  {
+    const int i = tid >> 2, p = tid & 3;
+    double a = 0.0;
+    for (int k = p; k <= i; k += 4) a += S[i * SLD + k] * ys[k];
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (p == 0) {
+      zs[i] = a;
+      z[i] = a;
+    }
+  }
+  __syncthreads();
+  {
+    const int j = tid >> 2, p = tid & 3;
+    double a = 0.0;
+    for (int k = j + p; k < 128; k += 4) a += S[k * SLD + j] * zs[k];
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    if (p == 0) alpha[j] = a;
+  }
+  if (!want_kinv) return;
+  // ---- K^-1 = X^T X: S <- X^T in place, then the lower tiles of S S^T on the matrix cores ---------------------------------
+  __syncthreads();
+  for (int idx = tid; idx < 128 * 128; idx += NT) {
+    const int i = idx >> 7, j = idx & 127;
+    if (j < i) {
+      const double v = S[i * SLD + j];
+      S[j * SLD + i] = v;
+      S[i * SLD + j] = 0.0;
+    }
+  }
+  __syncthreads();
+  f64x4 c[2][4];
+  wg_gemm128<true, TRI_SYM>(c, S, G, nullptr, 0, tid);
+  const int lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int wr = w >> 1, wc = w & 1;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+      if (GOGP_CT(nn) <= GOGP_RT(m)) {
+        // both triangles: the input-gradient kernel's mirror step takes the diagonal 32 x 32 tiles as already symmetric
+        // (the general path's tile kernel writes its diagonal tiles whole)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const long i = GOGP_RT(m) * 16 + fk + 4 * v, j = GOGP_CT(nn) * 16 + fr;
+          A[i * 256 + j] = c[m][nn][v];
+          A[j * 256 + i] = c[m][nn][v];
+        }
+      }
+}
+
+#ifndef GOGP_BUILD_TESTHOOKS
+void launch_tiny_eval(hipStream_t s, const DevParams *P, const double *X, const double *y, int64_t n, double *A, double *L,
+                      double *Dinv, double *z, double *alpha, long long *info, bool want_kinv) {
+  GOGP_KLAUNCH(tiny_eval_kernel, dim3(4, 1, (unsigned)gogp::tl_batch.k), dim3(NT), 0, s, P, X, y, (long)n, A, L, Dinv, z, alpha,
+               info, want_kinv ? 1 : 0, gogp::tl_batch.stride);
+}
+#endif
 
 #ifndef GOGP_BUILD_TESTHOOKS
 void launch_dinv256_blocks(hipStream_t s, const double *L, int64_t ld, double *Dinv, int nblk) {

@@ -93,6 +93,7 @@ struct gogp_handle {
   int head_remaining = 16;     // (measured, N = 16384: 3 / 16 72.7 ms, 3 / 24 72.8, 4 / 32 74.2, off 73.0-73.4)
   int chain_prio = -1;         // tile-kernel launches on the two chains raise their waves' issue priority (-1: by size)
   int64_t chain_tail = 0;      // chain_split = -1, large N beside the inverse: panel128 for the super-panels with at most this many rows left (0: none)
+  int tiny = 1;                // N <= 128 observations: one launch for the whole factorisation (api.hip: tiny_factorize)
   int chain_slabs = 0;         // chain_split = 2: slabs of 64 panel rows per workgroup (panel128.hip); 0: by the launch's size
   int chain_split = -1;        // 1: the diagonal block in two 128-halves, their products on the tile kernel; 2: panel128.hip (api.hip; -1: by size)
   int ktri = 1;                // panel solves skip the zero half of the block inverse (common.h: GemmGrid)

@@ -399,6 +399,9 @@ int gogp_profile_read_aux(gogp_handle *h, int cls, double *ms, int64_t *launches
  *                          evaluation is latency-bound (N <= 8192) or no fp64 inverse runs beside the factorisation
  *                          (Absorb, eager = 0); above that, beside the inverse, 0 -- and 2 for the super-panels with at
  *                          most "chain_tail" rows left                                                (default -1)
+ *   "tiny"         1 | 0   fp64, one GPU, N <= 128 observations (the reference's own case studies): Gram matrix, factor, block
+ *                          inverse, z, alpha and K^-1 in ONE launch of one workgroup instead of the general sweep's ~15
+ *                          dependent launches; 0: the general sweep                                   (default 1)
  *   "chain_slabs"  0..8    chain_split = 2: 64-row slabs of the panel per workgroup of the chain step; the result does
  *                          not depend on it; 0: one while the launch has at most a workgroup per compute unit, up to 4
  *                          beyond (measured at N = 16384: 1 / 2 / 4 slabs 30.1 / 32.0 / 35.4 ms Observe only) (default 0)

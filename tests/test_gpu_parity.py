@@ -597,6 +597,59 @@ def test_chain_step_result_does_not_depend_on_slabs_per_workgroup(rows_below):
         np.testing.assert_array_equal(L, outs[0])
 
 
+@pytest.mark.parametrize("name,D,simil,noise,ts,tn", CASES, ids=[c[0] for c in CASES])
+def test_tutorial_sized_evaluations_in_one_launch(gpmod, name, D, simil, noise, ts, tn):
+    """Option tiny (default on; gp/gp.go:89-239 at the reference's own sizes -- its case studies fit 20 .. 200 observations):
+    for N <= 128 the Gram matrix, the factor, the block inverse, z, alpha and K^-1 come from ONE launch of one workgroup
+    (diag256.hip: tiny_eval_kernel) instead of the general sweep's ~15 dependent launches.  Same numbers as the general sweep
+    -- LML, gradient, alpha, mu / sigma, the full-form gradient, candidates bit-equal to single calls, Absorb + Produce -- for
+    every kernel family, at the edge sizes 1 and 128, and the general sweep takes over at 129."""
+    rng = np.random.default_rng(len(name))
+    x = np.log(np.array(list(ts) + list(tn)))
+    for n in (1, 20, 128, 129):
+        X, y = _data(rng, n, D)
+        Z = rng.uniform(-0.1, 1.1, (5, D))
+        out = {}
+        for tiny in (0, 1):
+            g = gpmod.GP(D, simil, noise, X=X, Y=y)
+            g.set_option("tiny", tiny)
+            lml = g.Observe(x)
+            grad = g.Gradient()
+            alpha = g.Alpha.copy()
+            mu, sg = g.Produce(Z)
+            xs = np.stack([x, x + 0.02, x - 0.03])
+            cl, cg, cs = g.observe_gradient_candidates(xs)
+            assert list(cs) == [0, 0, 0] and cl[0] == lml
+            np.testing.assert_array_equal(cg[0], grad)
+            ThS, ThN = np.exp(x[:len(ts)]), np.exp(x[len(ts):])
+            g.ThetaSimil, g.ThetaNoise = ThS, ThN
+            g.Absorb(X, y)
+            mu_a, sg_a = g.Produce(Z)
+            full = np.concatenate([x, X.ravel(), y])
+            lml_f = g.Observe(full)
+            grad_f = g.Gradient()
+            out[tiny] = (lml, grad, alpha, mu, sg, mu_a, sg_a, lml_f, grad_f, g.L.copy())
+            g.close()
+        a, b = out[0], out[1]
+        # (default_noise: cond(K) ~ 1e10 -- two orders of summation differ by cond x eps there)
+        tl, tv = (1e-7, 1e-4) if name == "default_noise" else (1e-12, 1e-8)
+        assert abs(a[0] - b[0]) <= tl * max(1.0, abs(a[0])) and abs(a[7] - b[7]) <= tl * max(1.0, abs(a[7]))
+        for k in (1, 2, 3, 4, 5, 6, 8, 9):
+            np.testing.assert_allclose(b[k], a[k], rtol=tv, atol=tv * 0.1 * max(1.0, np.abs(a[k]).max()))
+        if n == 129:   # above 128 both handles ran the general sweep
+            assert a[0] == b[0]
+            np.testing.assert_array_equal(a[1], b[1])
+    # not positive definite (gp/gp.go:228-230) through the one-launch form: the failing pivot as everywhere
+    Xd = 100.0 * np.arange(40, dtype=float)[:, None] * np.ones((1, D))
+    Xd[-1] = Xd[-2]
+    g = gpmod.GP(D, kernel.Normal if D == 1 else kernel.Scaled(kernel.Normal), kernel.ConstantNoise(0.0),
+                 ThetaSimil=[1.0] if D == 1 else [1.0, 1.0])
+    with pytest.raises(gpmod.FactorizeError) as ei:
+        g.Absorb(Xd, np.ones(40))
+    assert ei.value.pivot == 39
+    g.close()
+
+
 def _same_results(a, b):
     assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(a[0]))
     np.testing.assert_allclose(b[1], a[1], rtol=1e-9, atol=1e-9 * np.abs(a[1]).max())
