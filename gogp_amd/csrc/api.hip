@@ -1212,7 +1212,7 @@ static int factorize_t(gogp_handle *h, bool eager) {
 }
 
 // ---- option "tiny" (default on): N <= 128 observations, the whole factorisation in ONE launch (diag256.hip: tiny_eval_kernel)
-// The reference's own case studies have 20 .. 200 observations (tutorial/data/*.csv); the general sweep is then a chain of
+// The reference's own case studies have 20 .. 44 observations (tutorial/data/*.csv); the general sweep is then a chain of
 // ~15 dependent launches (0.34 ms per Observe at N = 64, 30 us of it arithmetic).  Everything the later calls read is left
 // where the general path leaves it -- L, the block inverse, z, alpha, K^-1 (Observe) -- so Gradient, Produce, the factor
 // export and the lazy inverse after Absorb run unchanged; only Y = L^-T is not formed (nobody needs it once K^-1 exists).

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(NT) void dinv256_blocks_kernel(const double *__rest
 }
 
 // ---- tutorial-sized evaluations: N <= 128 observations in ONE workgroup, ONE launch ---------------------------------------
-// The reference's own case studies fit 20 ... 200 observations (tutorial/data/*.csv; BASELINE configs[0]: N = 64).  At that
+// The reference's own case studies fit 20 ... 44 observations (tutorial/data/*.csv; BASELINE configs[0]: N = 64).  At that
 // size the general sweep is fifteen dependent launches of a few microseconds each (kernel trace at N = 64: 0.34 ms per
 // Observe, of which the arithmetic is 30 us).  Here workgroup 0 does gp/gp.go:109-236 in one go -- the Gram matrix of
 // the n <= 128 observations into LDS (kern_eval.h: simil_value; identity padding as everywhere), its Cholesky factor

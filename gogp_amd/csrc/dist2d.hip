@@ -531,8 +531,7 @@ static int dist_factorize_t(gogp_handle *h, bool want_kinv) {
                     ldA);
   // fp32 evaluation, option "diag_fp64": my tiles of the global diagonal leave the float matrix here (widened once; every
   // later contribution is summed in fp64 from the float panel tiles: diagsyrk.hip, api.hip does the same per 256-block)
-  d->d64_on = sizeof(T) == 4 && h->diag_fp64 != 0 && d->dq_count > 0 && d->d64;
-  if (sizeof(T) == 4 && h->diag_fp64 != 0 && d->dq_count == 0) d->d64_on = false;
+  d->d64_on = sizeof(T) == 4 && h->diag_fp64 != 0 && d->dq_count > 0 && d->d64 != nullptr;
   if (d->d64_on)
     for (int t = 0; t < d->dq_count; ++t) {
       const int bi = d->dq_first + t * d->dq_step, bj = (pr + Pr * bi - pc) / Pc;

@@ -599,7 +599,7 @@ def test_chain_step_result_does_not_depend_on_slabs_per_workgroup(rows_below):
 
 @pytest.mark.parametrize("name,D,simil,noise,ts,tn", CASES, ids=[c[0] for c in CASES])
 def test_tutorial_sized_evaluations_in_one_launch(gpmod, name, D, simil, noise, ts, tn):
-    """Option tiny (default on; gp/gp.go:89-239 at the reference's own sizes -- its case studies fit 20 .. 200 observations):
+    """Option tiny (default on; gp/gp.go:89-239 at the reference's own sizes -- its case studies fit 20 .. 44 observations):
     for N <= 128 the Gram matrix, the factor, the block inverse, z, alpha and K^-1 come from ONE launch of one workgroup
     (diag256.hip: tiny_eval_kernel) instead of the general sweep's ~15 dependent launches.  Same numbers as the general sweep
     -- LML, gradient, alpha, mu / sigma, the full-form gradient, candidates bit-equal to single calls, Absorb + Produce -- for
