@@ -240,7 +240,7 @@ void launch_widen_diag_blocks(hipStream_t s, const float *A, int64_t ld, double 
 // the same for blocks of bs x bs (256 or 512) whose rows start row_stride floats apart (the diagonal tiles of a shard)
 void launch_diag_syrk_f64_tiles(hipStream_t s, const float *Lrows, int64_t ld, int64_t K, double *D64, int nblocks,
                                 int64_t row_stride, int bs);
-// panel128.hip (option "chain_panel"): one 128-column step of the Cholesky chain in one launch -- the diagonal 128-block of
+// panel128.hip (option "chain_split" = 2): one 128-column step of the Cholesky chain in one launch -- the diagonal 128-block of
 // half 0 / 1 of the 256-block at A is factored and the rows_below (multiple of 64) rows under it are solved against it
 void launch_panel128(hipStream_t s, const double *A, int64_t ld, double *Lout, int64_t ldl, int half, int64_t rows_below,
                      int64_t row0, int64_t nvalid, long long *info);

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(NT) void diag128_kernel(const double *__restrict__ 
 }
 
 // ---- the dense 256 x 256 inverses of nblk consecutive diagonal blocks of a finished factor, one workgroup each (option
-// "chain_panel", api.hip: the chain no longer forms them; the substitutions, the triangular inverse and Produce do need
+// "chain_split" = 2, api.hip: the chain no longer forms them; the substitutions, the triangular inverse and Produce do need
 // them).  blockIdx.x = b: the block at L + b * 256 * (ld + 1), its inverse at Dinv + b * 65536.
 __global__ __launch_bounds__(NT) void dinv256_blocks_kernel(const double *__restrict__ L, long ld, double *__restrict__ Dinv,
                                                              long bstride) {

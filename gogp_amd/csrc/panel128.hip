@@ -1,5 +1,5 @@
 // panel128.hip -- one 128-column step of the blocked Cholesky's dependency chain in ONE launch: the 128 x 128 diagonal
-// block is factored AND every row of the panel below it is solved against it (option "chain_panel", api.hip).
+// block is factored AND every row of the panel below it is solved against it (option "chain_split" = 2, api.hip).
 //
 // Reference counterpart: the diagonal-block factorisation and the panel solve (Dtrsm) of gonum's blocked Dpotrf behind
 // mat.Cholesky.Factorize (gp/gp.go:228); "not positive definite" is reported through *info (first failing pivot + 1).
