@@ -30,10 +30,12 @@ SGPR_SPILL_ALLOW = {
     # call hipcc chooses by itself (313,996 vs 336,912 cycles per 256-block), which also needs a 20-byte
     # private segment for the callee-saved VGPRs.  Round 4: 456 -> 140 (the 16x16 inverses read their coefficients
     # as LDS broadcasts instead of 240 v_readlane results that hipcc hoisted and spilled); what is left are the
-    # sixteen lane == j masks of panel16 (hoisted out of the column-block loop) and kernel arguments
-    r"diag256_kernel<true, false, \d+>": 160,
-    # one 128-half of the block on its own (option chain_split): the same potrf128_lds / inv16 code, the same masks
-    r"diag128_kernel": 110,
+    # sixteen lane == j masks of panel16 (hoisted out of the column-block loop) and kernel arguments.  Round 5: 140 -> 60
+    # (the pivot pass broadcasts with DPP, pivot16.h: no v_readlane results to hoist); what is left are kernel arguments and
+    # the products' loop state
+    r"diag256_kernel<true, false, \d+>": 64,
+    # one 128-half of the block on its own (option chain_split = 1): the same potrf128_lds / inv16 code (round 5: 91 -> 7)
+    r"diag128_kernel": 48,
     # cold path: only gogp_set_factor (restore of stored results) inverts blocks of an existing factor (round 4: 248 -> 6)
     r"diag256_kernel<false, false, \d+>": 48,
     # multi-term / periodic kernels keep the per-pair loop: kind, scale, period and length tables of up to
